@@ -1,0 +1,120 @@
+/* svlm.h -- C ABI of libsvlm_hip.so: the MI355X (gfx950) kernels of the streaming-VLM hot path.
+ *
+ * Drop-in boundary.  The reference (rahim-xelpmoc/streaming-vlm) is pure Python; its device work
+ * is done by third-party wheels (transformers 4.52.4 modules, flash_attn 2.8, torch 2.7.1).  Each
+ * entry point below replaces one of those call sites; the citation after "replaces:" is the
+ * reference file:line (relative to /root/reference/src/streaming_vlm/inference unless noted) that
+ * makes the call.  INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked [host]; bf16 data is raw uint16 bits;
+ *   - the caller owns all buffers (torch allocator) and passes the HIP stream (hipStream_t as void*);
+ *     kernels are stream-ordered, never synchronise, never allocate: safe under hipGraph capture;
+ *   - return value: 0 = ok, negative errno-style code otherwise (SVLM_EINVAL bad argument,
+ *     SVLM_ELAUNCH launch failure); svlm_last_error() returns the thread-local message;
+ *     nothing ever throws across the boundary;
+ *   - `len_dev` arguments: a device int32 holding the current KV length, so that one captured
+ *     decode-step graph can be replayed while the cache grows; pass NULL to use host values.
+ *
+ * KV pool layout (allocated by the caller, one per stream):
+ *     pool[layer][kv(0=K,1=V)][Hkv][n_slots][D]  bf16, keys UN-ROTATED (shrink mode,
+ *     qwen2/language_forward.py:89-103); slot_of[i] = slot of logical token i.
+ *     "k_planes"/"v_planes" below are &pool[layer][0] and &pool[layer][1].
+ * RoPE table: rope_cs[i][0:D/2] = cos, [D/2:D] = sin of logical position i, bf16, mrope-section
+ *     selected (built by svlm_mrope_table from the (3, L) position ids).
+ */
+#ifndef SVLM_H
+#define SVLM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVLM_OK 0
+#define SVLM_EINVAL (-22)
+#define SVLM_ELAUNCH (-5)
+
+#define SVLM_ACT_NONE 0
+#define SVLM_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x), VisionMlp (qwen2/vision_forward.py:49) */
+#define SVLM_ACT_GELU_ERF 2   /* nn.GELU(), PatchMerger (qwen2/vision_forward.py:80) */
+#define SVLM_ACT_SILU 3
+
+int svlm_abi_version(void);
+const char* svlm_last_error(void); /* [host] */
+int svlm_device_cus(void);
+
+/* C[M,N] = bf16(act(bf16(A[M,K].W[N,K]^T + bias)) + residual).  bias/residual may be NULL.
+ * replaces: nn.Linear / Conv3d-as-GEMM at qwen2/vision_forward.py:14,33,57,43-49,80 and
+ * qwen2/language_forward.py:80-82,161,201 (prefill rows). */
+int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                   void* C, int ldc, int M, int N, int K, int act, void* stream);
+
+/* y[N] = same epilogue for one row x[K] (decode step); y (bf16) and/or y_f32 (fp32 copy of the
+ * bf16-rounded value: the `.float()` of streaming_generate_qwen.py:73) may be NULL.
+ * replaces: the same Linear calls at T = 1 and lm_head on the last row (qwen2/model_forward.py:243). */
+int svlm_gemv_bf16(const void* x, const void* W, int ldw, const void* bias, const void* residual, void* y, float* y_f32,
+                   int N, int K, int act, void* stream);
+
+/* replaces: Qwen2RMSNorm (qwen2/language_forward.py:183,200,315). */
+int svlm_rmsnorm(const void* x, const void* w, void* y, int rows, int cols, float eps, void* stream);
+/* replaces: nn.LayerNorm of the ViT blocks and merger (qwen2/vision_forward.py:43-49,80). */
+int svlm_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, void* stream);
+/* y = bf16(a + b), n elements (residual adds, qwen2/language_forward.py:195,202). */
+int svlm_add(const void* a, const void* b, void* y, long long n, void* stream);
+/* h[r,:] = bf16(bf16(silu(gu[r,0:I])) * gu[r,I:2I])  (Qwen2MLP, qwen2/language_forward.py:201). */
+int svlm_silu_mul(const void* gu, void* h, int rows, int inter, void* stream);
+/* out[t] = idx[t] >= 0 ? table[idx[t]] : alt[-1-idx[t]]; idx read at idx[*idx_off + t] if idx_off != NULL.
+ * replaces: embed_tokens + masked_scatter of the vision rows (qwen2/model_forward.py:34,62-69). */
+int svlm_gather_rows(const void* table, const void* alt, const int* idx, const int* idx_off, void* out, int rows, int cols,
+                     void* stream);
+
+/* In-place 2-D rope on the q and k parts of the fused ViT qkv buffer (N,3,H,d); cosT/sinT fp32 (N,d/2).
+ * replaces: apply_rotary_pos_emb_vision (qwen2/vision_forward.py:27). */
+int svlm_vit_rope(void* qkv, const float* cosT, const float* sinT, int N, int H, int d, void* stream);
+/* Block-diagonal non-causal attention over n_seq sequences of seq_len rows; out (N, H*d).
+ * replaces: flash_attn_varlen_func (qwen2/vision_forward.py:30). */
+int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len, int H, int d, float scale, void* stream);
+
+/* rope_cs rows [start, start+count) from position ids pos3 (int32) or posf3 (fp32, Qwen2.5), each
+ * (3, pos_stride); inv_freq fp32 (D/2) computed by the host exactly as torch does.
+ * replaces: Qwen2VLRotaryEmbedding.forward + mrope section select (qwen2/language_forward.py:271,43-60). */
+int svlm_mrope_table(const int* pos3, const float* posf3, int pos_stride, const float* inv_freq, void* rope_cs, int start,
+                     int count, int head_dim, int sec_t, int sec_h, int sec_w, void* stream);
+
+/* Append T un-rotated K/V rows of one layer at logical rows base..base+T-1 (base = *len_dev or start).
+ * replaces: StreamingCache.update = torch.cat (generate/streaming_cache.py:72-73). */
+int svlm_kv_append(const void* k_new, int k_stride, const void* v_new, int v_stride, void* k_planes, void* v_planes,
+                   const int* slot_of, const int* len_dev, int start, int T, int Hkv, int D, int n_slots, void* stream);
+/* In-place defragmentation: for every plane, row src[i] -> row dst[i] (dst = free slots).
+ * replaces (together with host edits of slot_of): index_select eviction (inference.py:54-59), the
+ * 4-slice torch.cat row move (inference.py:106-107) and .contiguous() (inference.py:66-67). */
+int svlm_kv_move_rows(void* pool, long long n_planes, int n_slots, int D, const int* src, const int* dst, int n, void* stream);
+/* Dense (Hkv, L, D) copy of one K or V region in logical order (StreamingCache-compatible views). */
+int svlm_kv_gather(const void* planes, const int* slot_of, void* out, int L, int Hkv, int D, int n_slots, void* stream);
+
+/* Decode-step attention: q (Hq, D) un-rotated; length = (*len_dev if len_dev else 0) + len_add counts the
+ * row just appended; ws >= svlm_decode_attn_ws_bytes(Hq, max_len, chunk); out (Hq, D).
+ * replaces: post-cache M-RoPE + repeat_kv + _flash_attention_forward at q_len = 1
+ * (qwen2/language_forward.py:103,107-108,148-158). */
+long long svlm_decode_attn_ws_bytes(int Hq, int max_len, int chunk);
+int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of, const void* rope_cs,
+                              const int* len_dev, int len_add, void* out, void* ws, int Hq, int Hkv, int D, int n_slots,
+                              int max_len, int chunk, float scale, void* stream);
+/* Prefill attention: q (T, q_stride) un-rotated rows for logical positions L-T..L-1 (their K/V already
+ * appended), causal bottom-right aligned; out (T, o_stride).  replaces: same lines at q_len = T. */
+int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_planes, const void* v_planes, const int* slot_of,
+                               const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D, int n_slots,
+                               float scale, void* stream);
+
+/* seen[id] = 1 for ids[0..n).  (input to the repetition penalty) */
+int svlm_mark_seen(const int* ids, int n, void* seen, int V, void* stream);
+/* Repetition penalty + argmax (lowest index on ties) + device-side token feedback:
+ * tok_buf[state[1]+1] = token; state[1] += 1; state[0] += advance_kv; seen[token] = 1.
+ * replaces: logits processors + argmax + cat (generate/streaming_generate_qwen.py:75,99,104). */
+int svlm_penalty_argmax(const float* logits, int V, void* seen, float penalty, const int* suppress, int n_suppress, int* tok_buf,
+                        int* state, int advance_kv, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVLM_H */

@@ -1,0 +1,145 @@
+"""Generation loop + per-chunk streaming driver (oracle; test infrastructure only).
+
+Restates
+  * ``generate/streaming_generate_qwen.py:8-127`` (``_sample``: prefill + decode loop,
+    fp32 last-row logits :73, logits processors :75, argmax/multinomial :95-99, EOS :101-109)
+  * ``generate/prepare_generation.py:31-35,131-134`` (only the un-cached suffix is fed;
+    pixels dropped on decode steps; position_ids=None -> recomputed in forward)
+  * ``qwen2/model_forward.py:119-126`` + ``qwen2/language_forward.py:323-325`` (shrink mode:
+    rope index recomputed from the FULL ids every forward; ids padded by one 0 per step)
+  * ``inference.py:309-517`` (the per-chunk loop) on tokenizer-free synthetic inputs.
+HF's RepetitionPenaltyLogitsProcessor (transformers ``generation/logits_process.py``) is
+restated in ``repetition_penalty``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import kv_policy, qwen_range as qr
+from .model import ModelCfg, model_forward
+from .rope_index import get_rope_index
+
+
+def repetition_penalty(logits_f32: torch.Tensor, ids, penalty: float):
+    """score<0 -> score*penalty else score/penalty for every token id present in `ids`."""
+    if penalty == 1.0:
+        return logits_f32
+    idx = torch.unique(torch.as_tensor(ids, dtype=torch.long))
+    sc = logits_f32[idx]
+    logits_f32 = logits_f32.clone()
+    logits_f32[idx] = torch.where(sc < 0, sc * penalty, sc / penalty)
+    return logits_f32
+
+
+@dataclass
+class GenOut:
+    sequences: List[int]
+    past_key_values: object
+    logits: List[torch.Tensor] = field(default_factory=list)   # fp32 raw last-row logits per step
+
+
+def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=None, grid_thw=None,
+             max_new_tokens=20, rep_penalty=1.05, eos_ids=(151645, 151643), suppress_eos=False,
+             do_sample=False, temperature=1.0, generator: Optional[torch.Generator] = None,
+             keep_logits=False) -> GenOut:
+    """One ``model.generate(**inputs, past_key_values=kv, streaming_args=...)`` call."""
+    ids = list(ids)
+    sa_ids = list(ids)                       # streaming_args.input_ids (padded with 0 per forward)
+    out_logits = []
+    n_new = 0
+    first = True
+    while True:
+        kv_len = kv.get_seq_length()
+        new_ids = ids[kv_len:]                                              # prepare_generation.py:31-35
+        pos3 = get_rope_index(sa_ids, video_grid_thw, cfg.vision.spatial_merge_size,
+                              cfg.video_token_id, cfg.vision_start_token_id)   # model_forward.py:119-126
+        has_vid = cfg.video_token_id in new_ids
+        logits = model_forward(w, cfg, new_ids, kv, pos3,
+                               pixel_values if (first and has_vid) else None,
+                               grid_thw if (first and has_vid) else None)
+        first = False
+        sa_ids = sa_ids + [0]                                               # language_forward.py:323-325
+        raw = logits[-1].float()                                            # streaming_generate_qwen.py:73
+        if keep_logits:
+            out_logits.append(raw.clone())
+        sc = repetition_penalty(raw, ids, rep_penalty)                      # :75
+        if suppress_eos:
+            sc = sc.clone()
+            sc[list(eos_ids)] = float("-inf")
+        if do_sample:
+            probs = torch.softmax(sc / temperature, dim=-1)
+            nxt = int(torch.multinomial(probs, 1, generator=generator))
+        else:
+            nxt = int(torch.argmax(sc))                                     # :99
+        ids.append(nxt)
+        n_new += 1
+        if nxt in eos_ids or n_new >= max_new_tokens:                       # :101-109
+            break
+    return GenOut(ids, kv, out_logits)
+
+
+@dataclass
+class StreamCfg:
+    """Knobs of streaming_inference (inference.py:181-207) that affect indices."""
+    policy: str = "structural"            # "structural" (reference) | "sink_window" (BASELINE) | "none"
+    window_size: int = 16
+    text_round: int = 16
+    text_sink: Optional[int] = None
+    text_sliding_window: Optional[int] = None
+    sink: int = 4
+    window: int = 2048
+    max_new_tokens: int = 20              # MAX_TOKEN_PER_DURATION, inference.py:45
+    repetition_penalty: float = 1.05
+    suppress_eos: bool = False
+    assistant_start_bias: int = 3         # len(tok("<|im_start|>assistant\n"))  inference.py:228
+    assistant_end_bias: int = 2           # len(tok(" ...<|im_end|>"))           inference.py:229
+
+
+def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
+                   chunk_source: Callable[[int], tuple], keep_logits=False):
+    """The loop of inference.py:309-517 on synthetic inputs.
+
+    chunk_source(i) -> (chunk_ids: list[int], pixel_values (N,1176), grid_thw [[t,h,w]])
+    Returns dict(ids_per_chunk, new_tokens_per_chunk, kv_len_per_chunk, trace, logits).
+    """
+    kv = kv_policy.ListKV(cfg.text.num_layers)
+    prev_ids: Optional[List[int]] = None
+    grids: List[List[int]] = []
+    trace, new_tokens, kv_lens, all_logits, ids_hist = [], [], [], [], []
+    for i in range(n_chunks):
+        chunk_trace = []
+        # ---- process_past_kv (inference.py:319)
+        if prev_ids is not None:
+            if scfg.policy == "structural":
+                kv, prev_ids = kv_policy.process_past_kv(
+                    kv, i, prev_ids, scfg.text_round, scfg.window_size, scfg.text_sink,
+                    scfg.text_sliding_window, scfg.assistant_start_bias, scfg.assistant_end_bias, chunk_trace)
+            elif scfg.policy == "sink_window":
+                kv, prev_ids, _ = kv_policy.sink_window_policy(
+                    kv, prev_ids, kv.get_seq_length(), scfg.sink, scfg.window, chunk_trace)
+        trace.append(chunk_trace)
+        chunk_ids, pix, grid = chunk_source(i)
+        # ---- ids = cat(prev, new[skip dup "\n"])  (inference.py:397-406)
+        if prev_ids is None:
+            ids = list(chunk_ids)
+        elif prev_ids[-1] != qr.LF:
+            ids = prev_ids + list(chunk_ids)
+        else:
+            ids = prev_ids + list(chunk_ids)[1:]
+        grids = grids + [list(g) for g in grid]                             # :411-416 (never pruned)
+        cur_len = len(ids)
+        out = generate(w, cfg, ids, kv, grids, pix, grid, scfg.max_new_tokens, scfg.repetition_penalty,
+                       suppress_eos=scfg.suppress_eos, keep_logits=keep_logits)
+        gen = out.sequences
+        if gen[-1] != qr.IM_END:                                            # :457-459
+            gen = gen + [qr.IM_END]
+        new_tokens.append(gen[cur_len:])
+        kv_lens.append(kv.get_seq_length())
+        all_logits.append(out.logits)
+        prev_ids = list(gen)                                                # :482
+        ids_hist.append(list(gen))
+    return dict(ids=ids_hist, new_tokens=new_tokens, kv_len=kv_lens, trace=trace, logits=all_logits, kv=kv)

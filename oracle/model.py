@@ -1,0 +1,250 @@
+"""Model math of the streaming hot path in eager PyTorch (oracle; test infrastructure only).
+
+Weights are a flat ``dict[str, Tensor]`` using the HF ``Qwen2VLForConditionalGeneration``
+state-dict names (``model.visual.*``, ``model.language_model.*``, ``lm_head.weight``).
+All tensor math runs in the weights' dtype (bf16 on the BASELINE configs) with the
+rounding points of the reference's eager modules; attention is restated with
+flash-attention's published numerics (fp32 scores / softmax, P rounded to the
+activation dtype before P.V, fp32 accumulation, one final rounding) because the
+reference always routes Qwen2 attention through ``flash_attn``
+(``qwen2/patch_model.py:28-32``).
+
+Reference call sites (relative to /root/reference/src/streaming_vlm/inference):
+  ViT        qwen2/vision_forward.py:6-80
+  decoder    qwen2/language_forward.py:66-334 (post-cache M-RoPE :9-64, :89-103)
+  model      qwen2/model_forward.py:6-150, :195-256
+Third-party modules they invoke (transformers 4.52.4 ``modeling_qwen2_vl.py``:
+PatchEmbed, VisionMlp, PatchMerger, Qwen2RMSNorm, Qwen2MLP,
+Qwen2VLRotaryEmbedding, rotate_half, apply_rotary_pos_emb_vision) are restated here
+and pinned against the installed transformers in tests/test_oracle_vs_transformers.py.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class VisionCfg:
+    depth: int = 32
+    embed_dim: int = 1280
+    num_heads: int = 16
+    mlp_hidden: int = 5120
+    patch_size: int = 14
+    temporal_patch_size: int = 2
+    spatial_merge_size: int = 2
+    in_channels: int = 3
+
+
+@dataclass
+class TextCfg:
+    hidden_size: int = 1536
+    num_layers: int = 28
+    num_heads: int = 12
+    num_kv_heads: int = 2
+    head_dim: int = 128
+    intermediate_size: int = 8960
+    vocab_size: int = 151936
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: List[int] = field(default_factory=lambda: [16, 24, 24])
+    tie_word_embeddings: bool = True
+
+
+@dataclass
+class ModelCfg:
+    vision: VisionCfg
+    text: TextCfg
+    video_token_id: int = 151656
+    vision_start_token_id: int = 151652
+
+
+# --------------------------------------------------------------------------- ViT
+
+def vit_rot_pos_emb(grid_thw, head_dim: int, merge: int, theta: float = 10000.0):
+    """rot_pos_emb + VisionRotaryEmbedding (modeling_qwen2_vl.py:243-249, rot_pos_emb).
+    Returns fp32 freqs (N, head_dim/2): [h-freqs | w-freqs], rows in merge-block-major order."""
+    dim = head_dim // 2
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float) / dim))
+    out = []
+    for t, h, w in [[int(v) for v in g] for g in grid_thw]:
+        hpos = torch.arange(h).unsqueeze(1).expand(-1, w)
+        hpos = hpos.reshape(h // merge, merge, w // merge, merge).permute(0, 2, 1, 3).flatten()
+        wpos = torch.arange(w).unsqueeze(0).expand(h, -1)
+        wpos = wpos.reshape(h // merge, merge, w // merge, merge).permute(0, 2, 1, 3).flatten()
+        pos = torch.stack([hpos, wpos], dim=-1).repeat(t, 1)          # (t*h*w, 2)
+        fr = pos.unsqueeze(-1).float() * inv_freq                      # (N, 2, dim/2)
+        out.append(fr.flatten(1))
+    return torch.cat(out, 0)
+
+
+def rotate_half(x):
+    x1 = x[..., : x.shape[-1] // 2]
+    x2 = x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def flash_attention(q, k, v, causal_offset: Optional[int], scale: float):
+    """q (Hq, T, D), k/v (Hq, L, D) already GQA-expanded.  causal_offset=None: full
+    attention; else query i sees keys <= causal_offset + i.  flash-attn numerics."""
+    s = torch.matmul(q.float(), k.float().transpose(1, 2)) * scale          # fp32 scores
+    if causal_offset is not None:
+        T, L = q.shape[1], k.shape[1]
+        qi = torch.arange(T).unsqueeze(1) + causal_offset
+        kj = torch.arange(L).unsqueeze(0)
+        s = s.masked_fill((kj > qi).unsqueeze(0), float("-inf"))
+    m = s.max(dim=-1, keepdim=True).values
+    p = torch.exp(s - m)
+    l = p.sum(dim=-1, keepdim=True)
+    o = torch.matmul(p.to(q.dtype).float(), v.float()) / l                  # P rounded before P.V
+    return o.to(q.dtype)
+
+
+def quick_gelu(x):
+    return x * torch.sigmoid(1.702 * x)
+
+
+def vit_forward(w: dict, cfg: ModelCfg, pixel_values, grid_thw, prefix="model.visual."):
+    """streaming_visual_encoder_forward (qwen2/vision_forward.py:53-80)."""
+    vc = cfg.vision
+    dt = w[prefix + "patch_embed.proj.weight"].dtype
+    pw = w[prefix + "patch_embed.proj.weight"].reshape(vc.embed_dim, -1)
+    x = F.linear(pixel_values.to(dt), pw)                                    # Conv3d(k=s) == GEMM
+    hd = vc.embed_dim // vc.num_heads
+    freqs = vit_rot_pos_emb(grid_thw, hd, vc.spatial_merge_size)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos(), emb.sin()                                          # fp32 (N, hd)
+    # one attention sequence per temporal grid (vision_forward.py:62-70)
+    seqlens = []
+    for t, h, ww in [[int(v) for v in g] for g in grid_thw]:
+        seqlens += [h * ww] * t
+    N = x.shape[0]
+    for b in range(vc.depth):
+        p = f"{prefix}blocks.{b}."
+        h1 = F.layer_norm(x, (vc.embed_dim,), w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-6)
+        qkv = F.linear(h1, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"])
+        q, k, v = qkv.reshape(N, 3, vc.num_heads, hd).permute(1, 0, 2, 3).unbind(0)
+        # apply_rotary_pos_emb_vision: fp32 math, one rounding (modeling_qwen2_vl.py:225-236)
+        qf, kf = q.float(), k.float()
+        c, s = cos.unsqueeze(-2), sin.unsqueeze(-2)
+        q = (qf * c + rotate_half(qf) * s).to(dt)
+        k = (kf * c + rotate_half(kf) * s).to(dt)
+        outs = []
+        st = 0
+        for n in seqlens:
+            qs, ks, vs = (t_[st:st + n].transpose(0, 1) for t_ in (q, k, v))
+            outs.append(flash_attention(qs, ks, vs, None, 1.0 / math.sqrt(hd)).transpose(0, 1))
+            st += n
+        a = torch.cat(outs, 0).reshape(N, -1)
+        x = x + F.linear(a, w[p + "attn.proj.weight"], w[p + "attn.proj.bias"])
+        h2 = F.layer_norm(x, (vc.embed_dim,), w[p + "norm2.weight"], w[p + "norm2.bias"], 1e-6)
+        f1 = F.linear(h2, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
+        x = x + F.linear(quick_gelu(f1), w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+    # PatchMerger (modeling_qwen2_vl.py:277-290)
+    m = prefix + "merger."
+    x = F.layer_norm(x, (vc.embed_dim,), w[m + "ln_q.weight"], w[m + "ln_q.bias"], 1e-6)
+    x = x.view(-1, vc.embed_dim * vc.spatial_merge_size ** 2)
+    x = F.gelu(F.linear(x, w[m + "mlp.0.weight"], w[m + "mlp.0.bias"]))
+    return F.linear(x, w[m + "mlp.2.weight"], w[m + "mlp.2.bias"])
+
+
+# --------------------------------------------------------------------------- LLM
+
+def rms_norm(x, weight, eps):
+    """Qwen2RMSNorm: fp32 variance, cast back, then weight (modeling_qwen2_vl.py:96-110)."""
+    dt = x.dtype
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return weight * xf.to(dt)
+
+
+def mrope_cos_sin(pos3, head_dim, theta, mrope_section, dtype):
+    """Qwen2VLRotaryEmbedding.forward + the mrope-section select of
+    apply_multimodal_rotary_pos_emb (language_forward.py:43-60): returns cos, sin
+    (L, head_dim) in `dtype`, already section-selected."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    pos3 = torch.as_tensor(pos3)
+    freqs = pos3.float().unsqueeze(-1) * inv_freq                 # (3, L, hd/2); K=1 matmul == product
+    emb = torch.cat((freqs, freqs), dim=-1)                       # (3, L, hd)
+    cos, sin = emb.cos().to(dtype), emb.sin().to(dtype)
+    sec = list(mrope_section) * 2
+    cos = torch.cat([m[i % 3] for i, m in enumerate(cos.split(sec, dim=-1))], dim=-1)
+    sin = torch.cat([m[i % 3] for i, m in enumerate(sin.split(sec, dim=-1))], dim=-1)
+    return cos, sin
+
+
+def apply_rope(x, cos, sin):
+    """x (H, L, D), cos/sin (L, D): eager `x*cos + rotate_half(x)*sin` in x.dtype."""
+    return (x * cos.unsqueeze(0)) + (rotate_half(x) * sin.unsqueeze(0))
+
+
+def decoder_forward(w: dict, cfg: ModelCfg, x, kv, pos3, prefix="model.language_model."):
+    """streaming_language_model_forward in shrink mode (language_forward.py:212-334).
+
+    x     (T, H) input embeddings of the un-cached suffix
+    kv    ListKV holding UN-ROTATED keys (language_forward.py:95-97)
+    pos3  (3, L+T) position ids of the WHOLE sequence (model_forward.py:119-126)
+    Returns final-norm hidden (T, H).
+    """
+    tc = cfg.text
+    T = x.shape[0]
+    cos, sin = mrope_cos_sin(pos3, tc.head_dim, tc.rope_theta, tc.mrope_section, x.dtype)
+    G = tc.num_heads // tc.num_kv_heads
+    scale = 1.0 / math.sqrt(tc.head_dim)
+    for li in range(tc.num_layers):
+        p = f"{prefix}layers.{li}."
+        res = x
+        h = rms_norm(x, w[p + "input_layernorm.weight"], tc.rms_eps)
+        q = F.linear(h, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"])
+        k = F.linear(h, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"])
+        v = F.linear(h, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"])
+        q = q.view(T, tc.num_heads, tc.head_dim).transpose(0, 1)            # (Hq, T, D)
+        k = k.view(T, tc.num_kv_heads, tc.head_dim).transpose(0, 1).unsqueeze(0)
+        v = v.view(T, tc.num_kv_heads, tc.head_dim).transpose(0, 1).unsqueeze(0)
+        K, V = kv.update(k, v, li)                                          # un-rotated append
+        K, V = K[0], V[0]                                                   # (Hkv, L, D)
+        L = K.shape[1]
+        assert cos.shape[0] == L, (cos.shape, L)
+        qr_ = apply_rope(q, cos[-T:], sin[-T:])                             # right-aligned (:44-53)
+        Kr = apply_rope(K, cos, sin)                                        # ALL cached keys (:55-63)
+        Kr = Kr.repeat_interleave(G, dim=0)
+        Vr = V.repeat_interleave(G, dim=0)
+        a = flash_attention(qr_, Kr, Vr, L - T, scale)                      # causal, bottom-right aligned
+        a = a.transpose(0, 1).reshape(T, -1)
+        x = res + F.linear(a, w[p + "self_attn.o_proj.weight"])
+        res = x
+        h = rms_norm(x, w[p + "post_attention_layernorm.weight"], tc.rms_eps)
+        g = F.linear(h, w[p + "mlp.gate_proj.weight"])
+        u = F.linear(h, w[p + "mlp.up_proj.weight"])
+        x = res + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+    return rms_norm(x, w[prefix + "norm.weight"], tc.rms_eps)
+
+
+def lm_head_weight(w):
+    return w["lm_head.weight"] if "lm_head.weight" in w else w["model.language_model.embed_tokens.weight"]
+
+
+def model_forward(w: dict, cfg: ModelCfg, new_ids, kv, pos3, pixel_values=None, grid_thw=None,
+                  all_rows: bool = False):
+    """qwen2_vl_forward / model_forward (qwen2/model_forward.py:6-150,195-256) on the
+    un-cached suffix `new_ids`.  Returns logits (rows, V) in the model dtype; the
+    reference computes all T rows (:243) and consumes only the last one
+    (streaming_generate_qwen.py:73) -- `all_rows=False` returns just that row."""
+    ids_t = torch.as_tensor(new_ids, dtype=torch.long)
+    x = F.embedding(ids_t, w["model.language_model.embed_tokens.weight"])
+    if pixel_values is not None:
+        ve = vit_forward(w, cfg, pixel_values, grid_thw)
+        mask = ids_t == cfg.video_token_id
+        if int(mask.sum()) != ve.shape[0]:                                   # model_forward.py:56-61
+            raise ValueError(f"Video features and video tokens do not match: tokens: {int(mask.sum())}, features {ve.shape[0]}")
+        x = x.clone()
+        x[mask] = ve.to(x.dtype)                                             # masked_scatter, row order
+    h = decoder_forward(w, cfg, x, kv, pos3)
+    if not all_rows:
+        h = h[-1:]
+    return F.linear(h, lm_head_weight(w))

@@ -1,0 +1,75 @@
+"""ctypes binding of libsvlm_hip.so (C ABI declared in include/svlm.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module
+raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvlm_hip.so")
+
+SVLM_OK = 0
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
+
+
+class SvlmError(RuntimeError):
+    pass
+
+
+_p, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> (restype, argtypes); must list every symbol of include/svlm.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "svlm_abi_version": (_i, []),
+    "svlm_last_error": (C.c_char_p, []),
+    "svlm_device_cus": (_i, []),
+    "svlm_gemm_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "svlm_gemv_bf16": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "svlm_rmsnorm": (_i, [_p, _p, _p, _i, _i, _f, _p]),
+    "svlm_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
+    "svlm_add": (_i, [_p, _p, _p, _ll, _p]),
+    "svlm_silu_mul": (_i, [_p, _p, _i, _i, _p]),
+    "svlm_gather_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "svlm_vit_rope": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "svlm_vit_attn": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
+    "svlm_mrope_table": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "svlm_kv_append": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "svlm_kv_move_rows": (_i, [_p, _ll, _i, _i, _p, _p, _i, _p]),
+    "svlm_kv_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "svlm_decode_attn_ws_bytes": (_ll, [_i, _i, _i]),
+    "svlm_decode_attn_ropeload": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "svlm_prefill_attn_ropeload": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "svlm_mark_seen": (_i, [_p, _i, _p, _i, _p]),
+    "svlm_penalty_argmax": (_i, [_p, _i, _p, _f, _p, _i, _p, _p, _i, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly when it is absent (no CPU / torch fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvlmError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c \"import __graft_entry__ as g; "
+            f"g.build()\"` at the repo root (needs hipcc). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.svlm_abi_version() != 1:
+        raise SvlmError(f"libsvlm_hip.so ABI version {lib.svlm_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != SVLM_OK:
+        msg = load().svlm_last_error()
+        raise SvlmError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,84 @@
+// Shared device helpers for the svlm HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all conversions are explicit
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment (8 bf16, 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define SVLM_OK 0
+#define SVLM_EINVAL (-22)
+#define SVLM_ELAUNCH (-5)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+
+// round-to-nearest-even, the rounding torch uses for fp32 -> bf16 (NaN inputs do not occur here)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi_bf(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
+__device__ __forceinline__ void unpack8(const u32x4_t& v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = lo_bf(v[i]); f[2 * i + 1] = hi_bf(v[i]); }
+}
+__device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// activation codes shared with include/svlm.h
+#define SVLM_ACT_NONE 0
+#define SVLM_ACT_QUICK_GELU 1
+#define SVLM_ACT_GELU_ERF 2
+#define SVLM_ACT_SILU 3
+
+// y is the bf16-rounded linear output (as float); returns the activation with the eager
+// module's intermediate roundings (each torch op rounds to bf16).
+__device__ __forceinline__ float apply_act(float y, int act) {
+  if (act == SVLM_ACT_QUICK_GELU) {          // x * sigmoid(1.702 * x): three roundings
+    float t = rbf(1.702f * y);
+    float s = rbf(1.0f / (1.0f + expf(-t)));
+    return rbf(y * s);
+  } else if (act == SVLM_ACT_GELU_ERF) {     // nn.GELU(): one rounding
+    return rbf(0.5f * y * (1.0f + erff(y * 0.70710678118654752440f)));
+  } else if (act == SVLM_ACT_SILU) {         // F.silu: one rounding
+    return rbf(y / (1.0f + expf(-y)));
+  }
+  return y;
+}
+
+void svlm_set_error(const char* fmt, ...);
+#define SVLM_CHECK_ARG(cond, ...)                    \
+  do {                                               \
+    if (!(cond)) {                                   \
+      svlm_set_error(__VA_ARGS__);                   \
+      return SVLM_EINVAL;                            \
+    }                                                \
+  } while (0)
+int svlm_check_launch(const char* what);

@@ -1,0 +1,322 @@
+"""The per-chunk hot path on HIP kernels: ViT -> merger -> LLM prefill -> greedy decode.
+
+Host-side restatement of the reference's model forwards with every arithmetic step routed to the
+C ABI (``ops.HipOps``):
+  ViT        qwen2/vision_forward.py:53-80 (+ block :36-50, attention :6-34)
+  model      qwen2/model_forward.py:6-150 (embed gather, vision splice, shrink-mode positions)
+  decoder    qwen2/language_forward.py:66-334
+  generate   generate/streaming_generate_qwen.py:8-127 (_sample loop)
+Differences that do not change results: lm_head runs on the last row only (the reference computes
+all T rows, model_forward.py:243, and reads one, streaming_generate_qwen.py:73); decode steps feed
+the sampled token back on the device and replay one captured HIP graph instead of returning to
+Python per token; positions are computed once per chunk instead of once per forward.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import ACT_GELU_ERF, ACT_QUICK_GELU
+from .config import ModelConfig
+from .kv_pool import KVPool
+from .positions import rope_index_qwen2
+from .weights import EngineWeights
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class GenerateOutput:
+    sequences: List[int]
+    past_key_values: KVPool
+    logits: Optional[List[torch.Tensor]] = None      # fp32 last-row logits per forward (tests)
+    n_new: int = 0
+
+
+class SvlmEngine:
+    def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, max_len: int = 4096, max_new_tokens: int = 32,
+                 decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None):
+        if ops is None:
+            from .ops import HipOps
+            ops = HipOps()                      # raises when the HIP extension / GPU is missing
+        self.ops = ops
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.w = EngineWeights(state_dict, cfg, self.device)
+        tc, vc = cfg.text, cfg.vision
+        if tc.head_dim != 128 or sum(tc.mrope_section) * 2 != tc.head_dim:
+            raise ValueError("LLM head_dim must be 128 with mrope sections summing to 64")
+        self.max_len = int(max_len)
+        self.max_new = int(max_new_tokens)
+        if decode_chunk is None:
+            # split-KV chunk: enough workgroups (n_splits * Hkv) to cover the chip at the bounded window
+            target = max(1, 256 // tc.num_kv_heads)
+            decode_chunk = max(16, min(256, 16 * int(math.ceil(self.max_len / target / 16))))
+        self.decode_chunk = int(decode_chunk)
+        self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
+        dev = self.device
+        H, V = tc.hidden_size, tc.vocab_size
+        self.qd, self.kd = tc.num_heads * tc.head_dim, tc.num_kv_heads * tc.head_dim
+        # rope: inv_freq exactly as Qwen2VLRotaryEmbedding computes it (fp32, host)
+        inv = 1.0 / (tc.rope_theta ** (torch.arange(0, tc.head_dim, 2, dtype=torch.float) / tc.head_dim))
+        self.inv_freq = inv.to(dev)
+        self.pos3_dev = torch.zeros((3, self.max_len), dtype=torch.int32, device=dev)
+        self.rope_cs = torch.zeros((self.max_len, tc.head_dim), dtype=BF16, device=dev)
+        # sampling / feedback state
+        self.tok_buf = torch.zeros(self.max_new + 1, dtype=torch.int32, device=dev)
+        self.state = torch.zeros(2, dtype=torch.int32, device=dev)          # [kv_len, cur]
+        self.seen = torch.zeros(V, dtype=torch.uint8, device=dev)
+        self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
+        self.eos_dev = torch.tensor(list(cfg.eos_token_ids), dtype=torch.int32, device=dev)
+        self.ids_dev = torch.zeros(self.max_len, dtype=torch.int32, device=dev)
+        # decode-step static activations
+        self.d_x = torch.zeros(H, dtype=BF16, device=dev)
+        self.d_xn = torch.zeros(H, dtype=BF16, device=dev)
+        self.d_qkv = torch.zeros(self.qd + 2 * self.kd, dtype=BF16, device=dev)
+        self.d_attn = torch.zeros(self.qd, dtype=BF16, device=dev)
+        self.d_gu = torch.zeros(2 * tc.intermediate_size, dtype=BF16, device=dev)
+        self.d_h = torch.zeros(tc.intermediate_size, dtype=BF16, device=dev)
+        self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, self.decode_chunk, dev)
+        self._vit_rope_cache = {}
+        self._graph = None
+        self._graph_key = None
+        self._penalty = 1.0
+        self._suppress = None
+
+    # ------------------------------------------------------------------ cache
+    def new_cache(self, page_tokens: int = 16, slack: float = 1.0) -> KVPool:
+        tc = self.cfg.text
+        return KVPool(tc.num_layers, tc.num_kv_heads, tc.head_dim, self.max_len, self.device, self.ops, page_tokens, slack)
+
+    # ------------------------------------------------------------------ ViT
+    def _vit_rope(self, grid_thw):
+        key = tuple(tuple(int(v) for v in g) for g in grid_thw)
+        if key not in self._vit_rope_cache:
+            vc = self.cfg.vision
+            dim = vc.head_dim // 2
+            inv = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float) / dim))
+            m = vc.spatial_merge_size
+            out = []
+            for t, h, w in key:
+                hp = torch.arange(h).unsqueeze(1).expand(-1, w).reshape(h // m, m, w // m, m).permute(0, 2, 1, 3).flatten()
+                wp = torch.arange(w).unsqueeze(0).expand(h, -1).reshape(h // m, m, w // m, m).permute(0, 2, 1, 3).flatten()
+                pos = torch.stack([hp, wp], dim=-1).repeat(t, 1)
+                out.append((pos.unsqueeze(-1).float() * inv).flatten(1))
+            fr = torch.cat(out, 0)                                   # (N, d/2) = [h freqs | w freqs]
+            self._vit_rope_cache[key] = (fr.cos().contiguous().to(self.device), fr.sin().contiguous().to(self.device))
+        return self._vit_rope_cache[key]
+
+    def vision_forward(self, pixel_values, grid_thw):
+        """streaming_visual_encoder_forward: (N, C*T*P*P) patches -> (N / merge^2, hidden)."""
+        o, w, vc = self.ops, self.w, self.cfg.vision
+        grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
+        N = sum(t * h * ww for t, h, ww in grid)
+        if pixel_values.shape[0] != N or pixel_values.shape[1] != vc.patch_dim:
+            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {grid} (N={N}, patch_dim={vc.patch_dim})")
+        sizes = {h * ww for _, h, ww in grid}
+        if len(sizes) != 1:
+            raise ValueError("all temporal grids of one call must share h*w")
+        seq_len = sizes.pop()
+        n_seq = N // seq_len
+        pix = pixel_values.to(device=self.device, dtype=BF16).contiguous()
+        cosT, sinT = self._vit_rope(grid)
+        E, Hh, d = vc.embed_dim, vc.num_heads, vc.head_dim
+        x = o.gemm(pix, w.patch_embed)
+        h = torch.empty_like(x)
+        qkv = torch.empty((N, 3 * E), dtype=BF16, device=self.device)
+        a = torch.empty((N, E), dtype=BF16, device=self.device)
+        f = torch.empty((N, vc.mlp_hidden), dtype=BF16, device=self.device)
+        scale = 1.0 / math.sqrt(d)
+        for bw in w.vit:
+            o.layernorm(x, bw["n1w"], bw["n1b"], 1e-6, out=h)
+            o.gemm(h, bw["qkv_w"], bias=bw["qkv_b"], out=qkv)
+            o.vit_rope(qkv, cosT, sinT, Hh, d)
+            o.vit_attn(qkv, n_seq, seq_len, Hh, d, scale, out=a)
+            o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
+            o.layernorm(x, bw["n2w"], bw["n2b"], 1e-6, out=h)
+            o.gemm(h, bw["fc1_w"], bias=bw["fc1_b"], out=f, act=ACT_QUICK_GELU)
+            o.gemm(f, bw["fc2_w"], bias=bw["fc2_b"], residual=x, out=x)
+        mg = w.merger
+        o.layernorm(x, mg["ln_w"], mg["ln_b"], 1e-6, out=h)
+        m2 = vc.spatial_merge_size ** 2
+        hm = h.view(N // m2, E * m2)
+        g1 = o.gemm(hm, mg["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
+        return o.gemm(g1, mg["w2"], bias=mg["b2"])
+
+    # ------------------------------------------------------------------ LLM
+    def _prefill(self, c: KVPool, idx_dev, vis, T: int, L_before: int):
+        o, w, tc = self.ops, self.w, self.cfg.text
+        H, qd, kd = tc.hidden_size, self.qd, self.kd
+        L = L_before + T
+        dev = self.device
+        x = torch.empty((T, H), dtype=BF16, device=dev)
+        o.gather_rows(w.embed, vis, idx_dev, x)
+        xn = torch.empty_like(x)
+        qkv = torch.empty((T, qd + 2 * kd), dtype=BF16, device=dev)
+        attn = torch.empty((T, qd), dtype=BF16, device=dev)
+        gu = torch.empty((T, 2 * tc.intermediate_size), dtype=BF16, device=dev)
+        hm = torch.empty((T, tc.intermediate_size), dtype=BF16, device=dev)
+        scale = 1.0 / math.sqrt(tc.head_dim)
+        for li, lw in enumerate(w.layers):
+            o.rmsnorm(x, lw["ln1"], tc.rms_eps, out=xn)
+            o.gemm(xn, lw["qkv_w"], bias=lw["qkv_b"], out=qkv)
+            o.kv_append(qkv[:, qd:qd + kd], qkv[:, qd + kd:], c.pool, li, c.slot_of_dev, L_before, T)
+            o.prefill_attn(qkv[:, :qd], c.pool, li, c.slot_of_dev, self.rope_cs, attn, T, L, tc.num_heads, scale)
+            o.gemm(attn, lw["o_w"], residual=x, out=x)
+            o.rmsnorm(x, lw["ln2"], tc.rms_eps, out=xn)
+            o.gemm(xn, lw["gu_w"], out=gu)
+            o.silu_mul(gu, out=hm)
+            o.gemm(hm, lw["down_w"], residual=x, out=x)
+        last = x[T - 1:T].contiguous()
+        o.rmsnorm(last, w.final_norm, tc.rms_eps, out=self.d_xn.view(1, H))
+        o.gemv(self.d_xn, w.lm_head, out_f32=self.logits)
+
+    def _decode_step_launch(self, c: KVPool):
+        """One token: every kernel reads the KV length / token index from `self.state` on the device."""
+        o, w, tc = self.ops, self.w, self.cfg.text
+        H, qd, kd = tc.hidden_size, self.qd, self.kd
+        kv_len = self.state[0:1]
+        scale = 1.0 / math.sqrt(tc.head_dim)
+        x1 = self.d_x.view(1, H)
+        o.gather_rows(w.embed, None, self.tok_buf, x1, idx_off=self.state[1:2])
+        k_new = self.d_qkv[qd:qd + kd].view(1, kd)
+        v_new = self.d_qkv[qd + kd:].view(1, kd)
+        for li, lw in enumerate(w.layers):
+            o.rmsnorm(self.d_x, lw["ln1"], tc.rms_eps, out=self.d_xn)
+            o.gemv(self.d_xn, lw["qkv_w"], bias=lw["qkv_b"], out=self.d_qkv)
+            o.kv_append(k_new, v_new, c.pool, li, c.slot_of_dev, 0, 1, len_dev=kv_len)
+            o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
+                          self.max_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
+            o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
+            o.rmsnorm(self.d_x, lw["ln2"], tc.rms_eps, out=self.d_xn)
+            o.gemv(self.d_xn, lw["gu_w"], out=self.d_gu)
+            o.silu_mul(self.d_gu.view(1, -1), out=self.d_h.view(1, -1))
+            o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)
+        o.rmsnorm(self.d_x, w.final_norm, tc.rms_eps, out=self.d_xn)
+        o.gemv(self.d_xn, w.lm_head, out_f32=self.logits)
+
+    def _sample_launch(self, advance_kv: int):
+        self.ops.penalty_argmax(self.logits, self.seen if self._penalty != 1.0 else None, self._penalty, self._suppress,
+                                self.tok_buf, self.state, advance_kv)
+
+    def _decode_step(self, c: KVPool):
+        if not self.use_graph:
+            self._decode_step_launch(c)
+            self._sample_launch(1)
+            return
+        key = (id(c), self._penalty, self._suppress is not None)
+        if self._graph is None or self._graph_key != key:
+            # capture once per (cache, sampling config); state is restored because capture does not execute
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_step_launch(c)
+                self._sample_launch(1)
+            self._graph, self._graph_key = g, key
+        self._graph.replay()
+
+    # ------------------------------------------------------------------ generate
+    def generate(self, ids: Sequence[int], cache: Optional[KVPool], video_grid_thw, pixel_values=None, grid_thw=None,
+                 max_new_tokens: int = 20, repetition_penalty: float = 1.05, do_sample: bool = False, temperature: float = 1.0,
+                 suppress_eos: bool = False, keep_logits: bool = False, generator=None) -> GenerateOutput:
+        cfg, tc, o = self.cfg, self.cfg.text, self.ops
+        ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+        if cache is None:
+            cache = self.new_cache()
+        cache.release_reserved()
+        L_before, L_ids = cache.length, int(ids.shape[0])
+        T = L_ids - L_before
+        if T < 1:
+            raise ValueError(f"nothing to forward: {L_ids} ids but {L_before} rows already cached")
+        if max_new_tokens < 1 or max_new_tokens > self.max_new:
+            raise ValueError(f"max_new_tokens={max_new_tokens} outside [1, {self.max_new}]")
+        if L_ids + max_new_tokens > self.max_len:
+            raise MemoryError(f"sequence {L_ids}+{max_new_tokens} exceeds engine max_len {self.max_len}")
+        dev = self.device
+        # ---- shrink-mode positions for the whole (pruned) sequence + the tokens to be generated
+        pos, nxt = rope_index_qwen2(ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
+        n_rows = L_ids + max_new_tokens
+        pos_full = np.empty((3, n_rows), dtype=np.int32)
+        pos_full[:, :L_ids] = pos
+        pos_full[:, L_ids:] = nxt + np.arange(max_new_tokens, dtype=np.int32)
+        self.pos3_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
+        o.mrope_table(self.pos3_dev, self.inv_freq, self.rope_cs, 0, n_rows, tc.mrope_section)
+        cache.reserve(T + max_new_tokens)
+        cache.sync_device()
+        # ---- embeddings of the un-cached suffix (vision rows spliced in order)
+        new_ids = ids[L_before:]
+        vmask = new_ids == cfg.video_token_id
+        vis = None
+        idx = new_ids.astype(np.int32)
+        if vmask.any():
+            if pixel_values is None:
+                raise ValueError("video tokens in the un-cached suffix but no pixel_values_videos")
+            vis = self.vision_forward(pixel_values, grid_thw)
+            n_tok = int(vmask.sum())
+            if n_tok != vis.shape[0]:
+                raise ValueError(f"Video features and video tokens do not match: tokens: {n_tok}, features {vis.shape[0]}")
+            idx = idx.copy()
+            idx[vmask] = -1 - np.arange(n_tok, dtype=np.int32)
+        idx_dev = torch.from_numpy(idx).to(dev)
+        # ---- sampling state
+        self._penalty = float(repetition_penalty)
+        self._suppress = self.eos_dev if suppress_eos else None
+        if self._penalty != 1.0:
+            self.ids_dev[:L_ids].copy_(torch.from_numpy(ids.astype(np.int32)))
+            self.seen.zero_()
+            o.mark_seen(self.ids_dev, L_ids, self.seen)
+        self.state.copy_(torch.tensor([L_ids, -1], dtype=torch.int32))
+        logits_out = [] if keep_logits else None
+
+        self._prefill(cache, idx_dev, vis, T, L_before)
+        if keep_logits:
+            logits_out.append(self.logits.detach().cpu().clone())
+        if do_sample:
+            return self._generate_sampling(ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out)
+        self._sample_launch(0)
+        for _ in range(1, max_new_tokens):
+            self._decode_step(cache)
+            if keep_logits:
+                logits_out.append(self.logits.detach().cpu().clone())
+        toks = self.tok_buf[:max_new_tokens].cpu().numpy()               # the one host sync of the chunk
+        n_new = max_new_tokens
+        for j, t in enumerate(toks):
+            if int(t) in cfg.eos_token_ids:
+                n_new = j + 1
+                break
+        cache.commit(L_ids + n_new - 1)
+        cache.release_reserved()
+        seq = ids.tolist() + [int(t) for t in toks[:n_new]]
+        return GenerateOutput(seq, cache, logits_out, n_new)
+
+    def _generate_sampling(self, ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out):
+        """do_sample=True (the reference's default: T=0.9, multinomial, streaming_generate_qwen.py:95-97).
+        Token choice runs through torch on the device (RNG plumbing); forwards are the same kernels."""
+        cfg = self.cfg
+        new = []
+        seen_ids = torch.from_numpy(np.unique(ids)).to(self.device)
+        for step in range(max_new_tokens):
+            sc = self.logits.clone()
+            if self._penalty != 1.0:
+                s = sc[seen_ids]
+                sc[seen_ids] = torch.where(s < 0, s * self._penalty, s / self._penalty)
+            if self._suppress is not None:
+                sc[self._suppress.long()] = float("-inf")
+            probs = torch.softmax(sc / temperature, dim=-1)
+            tok = int(torch.multinomial(probs, 1, generator=generator))
+            new.append(tok)
+            seen_ids = torch.cat([seen_ids, torch.tensor([tok], device=self.device)])
+            if tok in cfg.eos_token_ids or step + 1 >= max_new_tokens:
+                break
+            self.tok_buf[step:step + 1].copy_(torch.tensor([tok], dtype=torch.int32))
+            self.state.copy_(torch.tensor([L_ids + step, step], dtype=torch.int32))
+            self._decode_step_launch(cache)
+            if logits_out is not None:
+                logits_out.append(self.logits.detach().cpu().clone())
+        cache.commit(L_ids + len(new) - 1)
+        cache.release_reserved()
+        return GenerateOutput(ids.tolist() + new, cache, logits_out, len(new))

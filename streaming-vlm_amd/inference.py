@@ -1,0 +1,381 @@
+"""Per-chunk streaming driver on the HIP engine -- keeps the call surface of the reference's
+``src/streaming_vlm/inference/inference.py`` (``streaming_inference`` :181-522 with the same keyword
+names, ``process_past_kv`` :87-172, ``prune_id_and_kv_cache`` :50-61, ``contiguous_id_and_kv`` :63-68,
+``load_model_and_processor`` :70-85) so the reference's harnesses (eval/efficiency/efficiency_test.py:74,
+eval/livesports3kcc/distributed_generate_streaming.py:100) can call it as a drop-in.
+
+What changes underneath: ids live on the host (no ``.tolist()`` device syncs), the KV cache is a
+``KVPool`` whose prune/move are slot-table edits, and ``model.generate`` runs the HIP kernels.
+Build-defined additions are keyword-only: ``kv_policy="sink_window"`` with ``sink``/``window``
+(BASELINE's token-count policy), ``do_sample``, ``suppress_eos``, ``trace``.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+from typing import List, Optional
+
+import torch
+
+from .config import IM_END, VIDEO_PAD, VISION_END, VISION_START
+from .get_qwen_range import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range
+from .kv_pool import KVPool
+from .patch_model import StreamingQwen2VL, convert_qwen2_to_streaming
+from .streaming_args import StreamingArgs
+from .synthetic import SyntheticProcessor, SyntheticVideo
+from .vtt_utils import open_vtt, sec2ts
+
+TOTAL_VIDEO_DURATION = 6000
+DEFAULT_CHUNK_DURATION = 1
+DEFAULT_WINDOW_SIZE = 16
+DEFAULT_TEXT_ROUND = 16
+DEFAULT_TEXT_SINK = 512
+DEFAULT_TEXT_SLIDING_WINDOW = 512
+DEFAULT_TEMPERATURE = 0.9
+DEFAULT_REPETITION_PENALTY = 1.05
+MAX_TOKEN_PER_DURATION = 20
+FPS = float(os.environ.get("QWENVL_FPS", "2.0"))       # the reference reads qwen_vl_utils.FPS (env-driven)
+
+
+# ----------------------------------------------------------------------------- KV / id edits
+def prune_id_and_kv_cache(input_ids, past_key_values, start_index, end_index, trace=None):
+    """Delete the CLOSED interval [start_index, end_index] from the ids and from every layer's K, V."""
+    input_ids = torch.cat([input_ids[:, :start_index], input_ids[:, end_index + 1:]], dim=1)
+    if past_key_values is not None:
+        past_key_values.release_reserved()
+        past_key_values.prune(int(start_index), int(end_index))
+    if trace is not None:
+        trace.append(("prune", int(start_index), int(end_index)))
+    return input_ids, past_key_values
+
+
+def resort_id_and_kv(input_ids, past_key_values, src_start_idx, src_end_idx, dst_idx, trace=None):
+    """Move [src_start_idx, src_end_idx] to directly after dst_idx (assistant text -> previous-text block)."""
+    assert dst_idx < src_start_idx <= src_end_idx
+    input_ids = torch.cat([input_ids[:, :dst_idx + 1], input_ids[:, src_start_idx:src_end_idx + 1],
+                           input_ids[:, dst_idx + 1:src_start_idx], input_ids[:, src_end_idx + 1:]], dim=1)
+    if past_key_values is not None:
+        past_key_values.release_reserved()
+        past_key_values.move(int(src_start_idx), int(src_end_idx), int(dst_idx))
+    if trace is not None:
+        trace.append(("move", int(src_start_idx), int(src_end_idx), int(dst_idx)))
+    return input_ids, past_key_values
+
+
+def contiguous_id_and_kv(input_ids, past_key_values):
+    """The reference re-materialises every layer (.contiguous()); the pool needs nothing unless it is
+    fragmented enough to defragment in place."""
+    if past_key_values is not None and past_key_values.fragmentation() > 0.5:
+        past_key_values.defragment()
+    return input_ids.contiguous(), past_key_values
+
+
+def snap_cut_end(ids_row, end: int) -> int:
+    """Extend a token-count cut forward to <|vision_end|> when it would split a vision span."""
+    t = int(ids_row[end])
+    if t not in (VISION_START, VIDEO_PAD):
+        return end
+    n = ids_row.shape[0]
+    j = end
+    while j < n and int(ids_row[j]) != VISION_END:
+        j += 1
+    if j >= n:
+        raise ValueError("unterminated vision span")
+    return j
+
+
+def sink_window_evict(past_key_values, input_ids, sink: int, window: int, trace=None):
+    """BASELINE policy: while L_kv > sink + window: prune(ids, kv, sink, L_kv - window - 1)."""
+    kv_len = past_key_values.get_seq_length()
+    while kv_len > sink + window:
+        end = snap_cut_end(input_ids[0], kv_len - window - 1)
+        input_ids, past_key_values = prune_id_and_kv_cache(input_ids, past_key_values, sink, end, trace)
+        kv_len = past_key_values.get_seq_length()
+    return past_key_values, input_ids
+
+
+def process_past_kv(past_key_values, i, text_round, visual_round, full_conversation_history, prev_generated_ids,
+                    assistant_start_bias, assistant_end_bias, recent_video_window_clips, recent_pixel_values_videos,
+                    text_sink, text_sliding_window, trace=None):
+    """Structural eviction at the start of round i (reference inference.py:87-172)."""
+    ids, kv = prev_generated_ids, past_key_values
+    hist = full_conversation_history
+    if i >= text_round:
+        # oldest retained assistant turn: its text migrates into the "previous text" block
+        assert hist[0]["role"] == "previous text"
+        assert hist[-2 * text_round]["role"] == "user" and hist[-(2 * text_round - 1)]["role"] == "assistant"
+        hist[0]["content"] += hist[-(2 * text_round - 1)]["content"][:-4]
+        a_s, a_e = get_qwen_range(ids, "assistant", 0)
+        _, p_e = get_qwen_range(ids, "previous text", 0, contain_lf=False)
+        src_s = a_s + assistant_start_bias
+        src_e = a_e - assistant_end_bias - (1 if int(ids[0, a_e]) == TOKEN_IDS["\n"] else 0)
+        if src_s <= src_e:
+            ids, kv = resort_id_and_kv(ids, kv, src_s, src_e, p_e - 1, trace)
+        user_turn = hist[-2 * text_round]["content"]
+        for k, item in enumerate(user_turn):
+            if item["type"] == "text":
+                del user_turn[k]
+                break
+        del hist[-(2 * text_round - 1)]
+        if visual_round > text_round:
+            u_s, u_e = get_qwen_range(ids, "user_text", -text_round, contain_lf=False)
+            ids, kv = prune_id_and_kv_cache(ids, kv, u_s, u_e, trace)
+        a_s, a_e = get_qwen_range(ids, "assistant", -text_round)
+        ids, kv = prune_id_and_kv_cache(ids, kv, a_s, a_e, trace)
+    if i >= visual_round:
+        recent_video_window_clips.pop(0)
+        recent_pixel_values_videos.pop(0)
+        if visual_round < text_round:
+            turn = hist[-2 * visual_round]
+            turn["content"] = [item for item in turn["content"] if item["type"] != "video"]
+            v_s, v_e = get_qwen_range(ids, "vision", 0)
+            ids, kv = prune_id_and_kv_cache(ids, kv, v_s, v_e, trace)
+    if i >= max(visual_round, text_round):
+        del hist[1]
+        u_s, u_e = get_qwen_range(ids, "user", 0)
+        ids, kv = prune_id_and_kv_cache(ids, kv, u_s, u_e, trace)
+    if i > 0:
+        if text_sink is not None or text_sliding_window is not None:
+            p_s, p_e = get_qwen_range(ids, "previous text", 0)
+            cut_s = p_s + text_sink + 4 if text_sink is not None else p_s
+            cut_e = p_e - text_sliding_window - 1 if text_sliding_window is not None else p_e
+            if cut_s <= cut_e:
+                ids, kv = prune_id_and_kv_cache(ids, kv, cut_s, cut_e, trace)
+        ids, kv = contiguous_id_and_kv(ids, kv)
+    return kv, ids, recent_video_window_clips, recent_pixel_values_videos
+
+
+# ----------------------------------------------------------------------------- loading
+def load_model_and_processor(model_path, model_base="Qwen2_5"):
+    """HF checkpoint -> converted model + AutoProcessor (needs local weights; nothing is downloaded).
+    ``random:<2b|7b|tiny>[:seed]`` builds random-init weights of the real shapes with the synthetic processor."""
+    if model_path.startswith("random:"):
+        from . import config as C
+        from .weights import random_state_dict
+        parts = model_path.split(":")
+        cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "tiny": C.tiny}[parts[1]]()
+        seed = int(parts[2]) if len(parts) > 2 else 0
+        return StreamingQwen2VL(cfg, random_state_dict(cfg, seed, "cuda"), "cuda"), SyntheticProcessor()
+    if model_base != "Qwen2":
+        raise NotImplementedError("only the Qwen2-VL family is on the HIP path (Qwen2.5-VL: SURVEY 8f-3)")
+    from transformers import AutoProcessor, Qwen2VLForConditionalGeneration
+    model = Qwen2VLForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map="cuda")
+    return convert_qwen2_to_streaming(model), AutoProcessor.from_pretrained(model_path, use_fast=False)
+
+
+def printq(*args, quiet=False, **kwargs):
+    if not quiet:
+        print(*args, **kwargs)
+
+
+# ----------------------------------------------------------------------------- main loop
+def streaming_inference(model_path="", video_path="", output_dir=None, model_base="Qwen2_5", model=None, processor=None,
+                        window_size=DEFAULT_WINDOW_SIZE, chunk_duration=DEFAULT_CHUNK_DURATION, text_round=DEFAULT_TEXT_ROUND,
+                        previous_text="", test_data_json=None, test_data_idx=None, pos_mode="shrink", all_text=False,
+                        skip_first_chunk=0, recompute=False, gt_json=None, gt_idx=None, text_sink=None,
+                        text_sliding_window=None, temperature=DEFAULT_TEMPERATURE, duration=TOTAL_VIDEO_DURATION,
+                        query="Commentate on this match", repetition_penalty=DEFAULT_REPETITION_PENALTY, quiet=False,
+                        emit_json=False, time_test=False, *, kv_policy="structural", sink=4, window=2048, do_sample=True,
+                        max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
+                        token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
+                        generator=None, keep_logits=False):
+    def _sync():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    if window_size % chunk_duration:
+        raise AssertionError("window_size must be divisible by chunk_duration")
+    if test_data_json is not None:
+        raise NotImplementedError("LMMDataset-driven input (training data pipeline) is outside the hot path")
+    if all_text:
+        raise NotImplementedError("all_text (1-D rope for LiveCC's training quirk) is a Qwen2.5-only switch")
+    if kv_policy not in ("structural", "sink_window", "none"):
+        raise ValueError(f"unknown kv_policy {kv_policy!r}")
+
+    streaming_args = StreamingArgs(pos_mode=pos_mode, all_text=all_text)
+    if model is None or processor is None:
+        model, processor = load_model_and_processor(model_path, model_base)
+    elif getattr(model, "_svlm_engine", None) is None:
+        if model_base != "Qwen2":
+            raise NotImplementedError("only the Qwen2-VL family is on the HIP path")
+        model = convert_qwen2_to_streaming(model)
+    device = model.device
+
+    assistant_start_bias = len(processor(text="<|im_start|>assistant\n")["input_ids"][0])
+    assistant_end_bias = len(processor(text=" ...<|im_end|>")["input_ids"][0])
+
+    gt_dict = None
+    if gt_json is not None:
+        with open(gt_json, "r") as f:
+            for ln, line in enumerate(f):
+                if ln == gt_idx:
+                    gt_dict = json.loads(line)
+                    break
+
+    if video is None:
+        video = SyntheticVideo.from_path(video_path)
+    if video is None:
+        raise FileNotFoundError(
+            f"{video_path!r}: real video decode (decord + bicubic resize) is host I/O outside the hot path; "
+            f"pass video=<object with .chunk(start_s, duration_s) -> uint8 (T,3,H,W)> or a synthetic://WxH@Ffps path")
+
+    if output_dir is not None:
+        if os.path.exists(output_dir):
+            os.remove(output_dir)
+        with open_vtt(output_dir):
+            pass
+        printq(f"Subtitles will be written to: {output_dir}", quiet=quiet)
+
+    past_key_values = None
+    full_conversation_history = []
+    prev_generated_ids = None
+    recent_video_window_clips, recent_pixel_values_videos = [], []
+    num_chunks = int((duration + chunk_duration - 1) // chunk_duration)
+    responses, time_results = [], []
+    printq(f"num_chunks: {num_chunks}", quiet=quiet)
+
+    for i in range(num_chunks):
+        _sync()
+        loop_start = time.perf_counter()
+        section_time = {k: 0.0 for k in ["PKV", "CHECK", "VIDEO", "INPUT", "GEN", "POST"]}
+        start_time = (i + skip_first_chunk) * chunk_duration
+        chunk_trace = [] if trace is not None else None
+
+        # ---- evict
+        _sync(); _t = time.perf_counter()
+        if prev_generated_ids is not None:
+            if kv_policy == "structural":
+                past_key_values, prev_generated_ids, recent_video_window_clips, recent_pixel_values_videos = process_past_kv(
+                    past_key_values, i, text_round=text_round, visual_round=window_size,
+                    full_conversation_history=full_conversation_history, prev_generated_ids=prev_generated_ids,
+                    assistant_start_bias=assistant_start_bias, assistant_end_bias=assistant_end_bias,
+                    recent_video_window_clips=recent_video_window_clips,
+                    recent_pixel_values_videos=recent_pixel_values_videos, text_sink=text_sink,
+                    text_sliding_window=text_sliding_window, trace=chunk_trace)
+            elif kv_policy == "sink_window":
+                past_key_values, prev_generated_ids = sink_window_evict(past_key_values, prev_generated_ids, sink, window, chunk_trace)
+                if len(recent_video_window_clips) >= window_size:
+                    recent_video_window_clips.pop(0)
+                    recent_pixel_values_videos.pop(0)
+        if trace is not None:
+            trace.append(chunk_trace)
+        _sync(); section_time["PKV"] += time.perf_counter() - _t
+
+        # ---- frames of this chunk
+        _sync(); _t = time.perf_counter()
+        try:
+            current_video_chunk = video.chunk(start_time, chunk_duration)
+        except Exception as e:                          # the reference breaks the loop on a decode failure (:343-345)
+            print(f"Error in streaming_inference: {e}")
+            break
+        recent_video_window_clips.append(current_video_chunk)
+        _sync(); section_time["VIDEO"] += time.perf_counter() - _t
+
+        # ---- prompt + patches
+        _sync(); _t = time.perf_counter()
+        prompt = f"Time={start_time:.1f}-{start_time + chunk_duration:.1f}s"
+        if i == 0:
+            user_content = [{"type": "text", "text": prompt}, {"type": "video", "video": video_path},
+                            {"type": "text", "text": query}]
+            full_conversation_history = [{"role": "previous text", "content": previous_text},
+                                         {"role": "user", "content": user_content}]
+            text = processor.apply_chat_template(full_conversation_history, tokenize=False, add_generation_prompt=True)
+        else:
+            user_content = [{"type": "text", "text": prompt},
+                            {"type": "video", "video": video_path, "start": start_time, "duration": chunk_duration}]
+            full_conversation_history.append({"role": "user", "content": user_content})
+            text = processor.apply_chat_template([{"role": "user", "content": user_content}], tokenize=False,
+                                                 add_generation_prompt=True)
+            text = "\n" + text[SYSTEM_PROMPT_OFFSET:]
+        inputs = processor(text=[text], videos=recent_video_window_clips[-1], padding=True, return_tensors="pt")
+        new_ids = inputs["input_ids"].cpu()
+        if prev_generated_ids is not None:
+            # the history ends with <|im_end|> (keep the new "\n") or already with "\n" (drop the duplicate)
+            if int(prev_generated_ids[0, -1]) != TOKEN_IDS["\n"]:
+                new_ids = torch.cat([prev_generated_ids, new_ids], dim=1)
+            else:
+                new_ids = torch.cat([prev_generated_ids, new_ids[:, 1:]], dim=1)
+        inputs["input_ids"] = new_ids
+        inputs["attention_mask"] = torch.ones_like(new_ids)
+        inputs["pixel_values_videos"] = inputs["pixel_values_videos"].to(device)
+        recent_pixel_values_videos.append(inputs["pixel_values_videos"])
+        streaming_args.input_ids = new_ids
+        if i == 0:
+            streaming_args.video_grid_thw = inputs["video_grid_thw"]
+        else:
+            streaming_args.video_grid_thw = torch.cat([streaming_args.video_grid_thw, inputs["video_grid_thw"]], dim=0)
+        current_input_len = new_ids.shape[1]
+        _sync(); section_time["INPUT"] += time.perf_counter() - _t
+
+        # ---- generate
+        _sync(); _t = time.perf_counter()
+        gen_kw = dict(max_new_tokens=max_new_tokens, use_cache=True, return_dict_in_generate=True, do_sample=do_sample,
+                      repetition_penalty=repetition_penalty, streaming_args=streaming_args, pad_token_id=IM_END,
+                      temperature=temperature, suppress_eos=suppress_eos, generator=generator, keep_logits=keep_logits)
+        if recompute:
+            if past_key_values is not None:
+                past_key_values.release_reserved()
+                past_key_values.truncate(0)
+            n_keep = len(recent_pixel_values_videos)
+            outputs = model.generate(input_ids=new_ids, attention_mask=inputs["attention_mask"],
+                                     pixel_values_videos=torch.cat(recent_pixel_values_videos, dim=0),
+                                     video_grid_thw=streaming_args.video_grid_thw[-n_keep:],
+                                     past_key_values=past_key_values, **gen_kw)
+        else:
+            outputs = model.generate(input_ids=new_ids, attention_mask=inputs["attention_mask"],
+                                     pixel_values_videos=inputs["pixel_values_videos"],
+                                     video_grid_thw=inputs["video_grid_thw"], past_key_values=past_key_values, **gen_kw)
+        _sync(); section_time["GEN"] += time.perf_counter() - _t
+
+        # ---- post
+        _sync(); _t = time.perf_counter()
+        generated_ids = outputs.sequences.cpu()
+        n_decoded = generated_ids.shape[1] - current_input_len
+        if int(generated_ids[0, -1]) != IM_END:
+            generated_ids = torch.cat([generated_ids, torch.tensor([[IM_END]])], dim=1)
+        newly_generated_ids = generated_ids[:, current_input_len:]
+        response = processor.batch_decode(newly_generated_ids, skip_special_tokens=True)[0]
+        responses.append({"response": response[:-4], "start_time": start_time, "end_time": start_time + chunk_duration})
+        if token_counts is not None:
+            token_counts.append(int(n_decoded))
+        if ids_log is not None:
+            ids_log.append({"ids": generated_ids[0].tolist(), "new": newly_generated_ids[0].tolist(),
+                            "kv_len": outputs.past_key_values.get_seq_length(), "logits": getattr(outputs, "logits", None)})
+        time_key = prompt
+        past_key_values = outputs.past_key_values
+        hms = lambda s: time.strftime("%H:%M:%S", time.gmtime(int(s)))
+        printq(f"Time={hms(start_time)}-{hms(start_time + chunk_duration)}: \033[1m\033[34m{response}\033[0m",
+               f"past_key_values: {past_key_values.get_seq_length() if past_key_values is not None else 0}", flush=True, quiet=quiet)
+        if emit_json:
+            sys.stdout.write(json.dumps({"type": "segment", "start": float(start_time), "end": float(start_time + chunk_duration),
+                                         "text": response[:-4]}, ensure_ascii=False) + "\n")
+            sys.stdout.flush()
+        prev_generated_ids = generated_ids.clone()
+        if gt_dict is not None and gt_dict[time_key]["phrase"] != response:
+            # teacher forcing: drop the rows of the wrong answer, splice the ground-truth tokens (reference :483-487)
+            printq(f"Decoded text [{response}] is incorrect. Use ground truth [{gt_dict[time_key]['phrase']}] instead", quiet=quiet)
+            if past_key_values.get_seq_length() > current_input_len:
+                past_key_values.release_reserved()
+                past_key_values.prune(current_input_len, past_key_values.get_seq_length() - 1)
+            response = gt_dict[time_key]["phrase"]
+            gt_ids = processor(text=[response + "<|im_end|>\n"])["input_ids"]
+            prev_generated_ids = torch.cat([new_ids, torch.as_tensor(gt_ids, dtype=torch.long).reshape(1, -1)], dim=1)
+        full_conversation_history.append({"role": "assistant", "content": response})
+        _sync(); section_time["POST"] += time.perf_counter() - _t
+
+        _sync()
+        loop_total = time.perf_counter() - loop_start
+        printq(f"[Loop {i}] total={loop_total:.3f}s | " + " | ".join(f"{k}={section_time[k]:.3f}s" for k in section_time),
+               flush=True, quiet=quiet)
+        if time_test:
+            time_results.append(section_time)
+        if output_dir is not None:
+            with open_vtt(output_dir) as vf:
+                vf.write(f"{sec2ts(start_time)} --> {sec2ts(start_time + chunk_duration)}\n Infer Time: {loop_total:.3f}s\n {response}\n\n")
+    if output_dir is not None:
+        printq(f"\nSubtitles saved to: {output_dir}\n", quiet=quiet)
+    if time_test:
+        return time_results
+    return responses

@@ -1,0 +1,191 @@
+"""Paged, slot-mapped KV pool with in-place eviction -- the replacement for the reference's
+``StreamingCache`` (generate/streaming_cache.py:6-74: a list of per-layer tensors re-allocated by
+``torch.cat`` on every step) and for ``prune_id_and_kv_cache`` / ``resort_id_and_kv`` /
+``contiguous_id_and_kv`` (inference.py:50-68,100-108: index_select / cat into fresh tensors).
+
+Device layout: ``pool[layer][kv][Hkv][n_slots][D]`` bf16 (keys un-rotated) sized once for the
+bounded stream; ``slot_of[i]`` (int32) maps logical token i to its slot.  Slots are handed out in
+pages of ``page_tokens`` consecutive rows so a chunk's rows stay contiguous; eviction and the
+assistant-text move edit ``slot_of`` on the host (O(L) int32) and free whole pages when their
+last live row goes; bytes move only on append and when ``defragment`` packs sparse pages.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+
+class KVPool:
+    def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_len: int, device, ops, page_tokens: int = 16,
+                 slack: float = 1.0):
+        """max_len: the largest logical length the stream ever reaches (sink + window + one chunk)."""
+        self.n_layers, self.Hkv, self.D = n_layers, n_kv_heads, head_dim
+        self.P = page_tokens
+        self.max_len = int(max_len)
+        n_pages = int(np.ceil(max_len * (1.0 + slack) / page_tokens)) + 2
+        self.n_pages = n_pages
+        self.n_slots = n_pages * page_tokens
+        self.device = device
+        self.ops = ops
+        self.pool = torch.zeros((n_layers, 2, n_kv_heads, self.n_slots, head_dim), dtype=torch.bfloat16, device=device)
+        self.slot_of = np.zeros(self.max_len, dtype=np.int32)         # logical -> slot
+        self.slot_of_dev = torch.zeros(self.max_len, dtype=torch.int32, device=device)
+        self.length = 0           # rows holding data (== past_key_values.get_seq_length())
+        self.reserved = 0         # rows with a slot assigned (>= length)
+        self.page_live = np.zeros(n_pages, dtype=np.int32)
+        self.free_pages = deque(range(n_pages))
+        self.open_page = -1
+        self.open_fill = page_tokens
+        self._dirty_from = 0
+        self.stats = dict(moved_rows=0, defrags=0, evicted_rows=0)
+
+    # ------------------------------------------------------------------ allocation
+    def _take_slot(self) -> int:
+        if self.open_fill >= self.P:
+            if not self.free_pages:
+                raise MemoryError("KV pool out of pages")
+            self.open_page = self.free_pages.popleft()
+            self.open_fill = 0
+        s = self.open_page * self.P + self.open_fill
+        self.open_fill += 1
+        self.page_live[self.open_page] += 1
+        return s
+
+    def _free_slot(self, s: int):
+        pg = s // self.P
+        self.page_live[pg] -= 1
+        if self.page_live[pg] == 0 and pg != self.open_page:
+            self.free_pages.append(pg)
+        elif self.page_live[pg] == 0 and pg == self.open_page:
+            # nothing live on the open page: restart it from row 0 instead of leaking its tail
+            self.open_fill = 0
+
+    def free_slots_available(self) -> int:
+        return len(self.free_pages) * self.P + (self.P - self.open_fill)
+
+    def reserve(self, n: int):
+        """Assign slots to logical rows [reserved, reserved + n)."""
+        if self.reserved + n > self.max_len:
+            raise MemoryError(f"KV length {self.reserved + n} exceeds the pool's max_len {self.max_len}")
+        if self.free_slots_available() < n:
+            self.defragment()
+            if self.free_slots_available() < n:
+                raise MemoryError("KV pool out of slots even after defragmentation")
+        self._dirty_from = min(self._dirty_from, self.reserved)
+        for i in range(n):
+            self.slot_of[self.reserved + i] = self._take_slot()
+        self.reserved += n
+
+    def commit(self, new_length: int):
+        assert new_length <= self.reserved
+        self.length = new_length
+
+    def release_reserved(self):
+        """Give back rows reserved beyond `length` (unused decode slots after EOS / end of chunk)."""
+        for i in range(self.length, self.reserved):
+            self._free_slot(int(self.slot_of[i]))
+        self.reserved = self.length
+
+    # ------------------------------------------------------------------ structural edits (no data movement)
+    def prune(self, start: int, end: int):
+        """Delete the CLOSED logical interval [start, end] (reference: prune_id_and_kv_cache)."""
+        assert self.reserved == self.length, "release_reserved() before editing the cache"
+        assert 0 <= start <= end < self.length, (start, end, self.length)
+        for s in self.slot_of[start:end + 1]:
+            self._free_slot(int(s))
+        n = end - start + 1
+        self.slot_of[start:self.length - n] = self.slot_of[end + 1:self.length].copy()
+        self.length -= n
+        self.reserved = self.length
+        self._dirty_from = min(self._dirty_from, start)
+        self.stats["evicted_rows"] += n
+
+    def move(self, src_s: int, src_e: int, dst: int):
+        """Move rows [src_s, src_e] to directly after row dst (reference: resort_id_and_kv)."""
+        assert self.reserved == self.length
+        assert dst < src_s <= src_e < self.length
+        so = self.slot_of
+        seg = so[src_s:src_e + 1].copy()
+        mid = so[dst + 1:src_s].copy()
+        so[dst + 1:dst + 1 + seg.size] = seg
+        so[dst + 1 + seg.size:src_e + 1] = mid
+        self._dirty_from = min(self._dirty_from, dst + 1)
+
+    def truncate(self, new_length: int):
+        assert self.reserved == self.length and 0 <= new_length <= self.length
+        if new_length < self.length:
+            self.prune(new_length, self.length - 1)
+
+    # ------------------------------------------------------------------ device sync / defragmentation
+    def sync_device(self):
+        """Upload the changed tail of slot_of (a few KB, once per chunk, stream-ordered)."""
+        lo, hi = self._dirty_from, self.reserved
+        if lo < hi:
+            self.slot_of_dev[lo:hi].copy_(torch.from_numpy(self.slot_of[lo:hi].copy()))
+        self._dirty_from = self.max_len
+
+    def fragmentation(self) -> float:
+        """Fraction of slots of non-free pages that hold no live row."""
+        used_pages = self.n_pages - len(self.free_pages)
+        if used_pages == 0:
+            return 0.0
+        return 1.0 - float(self.reserved) / float(used_pages * self.P)
+
+    def defragment(self):
+        """Pack the live rows of the sparsest pages into fresh pages, in place (svlm_kv_move_rows).
+        Sources and destinations are disjoint slot sets, so one launch moves every layer's rows."""
+        assert self.reserved == self.length
+        if self.length == 0:
+            return 0
+        so = self.slot_of[:self.length]
+        pages = so // self.P
+        live = self.page_live.copy()
+        # candidates: closed pages that are at most half full, sparsest first
+        cand = [int(p) for p in np.argsort(live) if 0 < live[p] <= self.P // 2 and p != self.open_page]
+        src_idx: List[int] = []
+        budget = self.free_slots_available()
+        for p in cand:
+            rows = np.flatnonzero(pages == p)
+            if len(src_idx) + rows.size > budget:
+                break
+            src_idx.extend(int(r) for r in rows)
+        if not src_idx:
+            return 0
+        src_idx.sort()
+        src = so[src_idx].copy()
+        dst = np.empty_like(src)
+        freed_after = []
+        for k, li in enumerate(src_idx):
+            dst[k] = self._take_slot()
+            so[li] = dst[k]
+        for s in src:
+            freed_after.append(int(s))
+        # launch the move BEFORE recycling the source pages
+        self.ops.kv_move_rows(self.pool, torch.from_numpy(src).to(self.device), torch.from_numpy(dst).to(self.device))
+        for s in freed_after:
+            self._free_slot(s)
+        self._dirty_from = 0
+        self.stats["moved_rows"] += len(src_idx)
+        self.stats["defrags"] += 1
+        return len(src_idx)
+
+    # ------------------------------------------------------------------ reference-compatible views
+    def get_seq_length(self) -> int:
+        return self.length
+
+    def layer_kv(self, layer: int):
+        """Dense (1, Hkv, L, D) K and V in logical order, like the tensors the reference's cache holds."""
+        self.sync_device()
+        k = self.ops.kv_gather(self.pool, layer, 0, self.slot_of_dev, self.length)
+        v = self.ops.kv_gather(self.pool, layer, 1, self.slot_of_dev, self.length)
+        return k.unsqueeze(0), v.unsqueeze(0)
+
+    def __iter__(self):
+        for i in range(self.n_layers):
+            yield self.layer_kv(i)
+
+    def __len__(self):
+        return self.n_layers

@@ -1,0 +1,262 @@
+"""Python face of the C ABI: one method per entry point of include/svlm.h, taking torch tensors.
+
+torch is used for device memory and streams only; every method validates shapes on the host
+(a faulting kernel can take the whole node down) and launches on torch's current stream, so the
+calls can be captured in a HIP graph (`torch.cuda.graph`).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, check
+
+BF16 = torch.bfloat16
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t, dtype, name, dims=None):
+    if not t.is_cuda:
+        raise _lib.SvlmError(f"{name}: tensor must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise _lib.SvlmError(f"{name}: dtype {t.dtype} != {dtype}")
+    if dims is not None and t.dim() != dims:
+        raise _lib.SvlmError(f"{name}: expected {dims}-D tensor, got shape {tuple(t.shape)}")
+    if t.dim() and t.stride(-1) != 1:
+        raise _lib.SvlmError(f"{name}: innermost dimension must be contiguous")
+
+
+class HipOps:
+    """The only ops backend the product ships."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SvlmError("no HIP device visible: the svlm hot path only runs on an MI355X (gfx950) GPU")
+
+    # ------------------------------------------------------------------ dense
+    def gemm(self, A, W, bias=None, residual=None, out=None, act=ACT_NONE):
+        _req(A, BF16, "gemm.A", 2); _req(W, BF16, "gemm.W", 2)
+        M, K = A.shape
+        N, K2 = W.shape
+        if K != K2:
+            raise _lib.SvlmError(f"gemm: A is {tuple(A.shape)} but W is {tuple(W.shape)}")
+        if out is None:
+            out = torch.empty((M, N), dtype=BF16, device=A.device)
+        _req(out, BF16, "gemm.out", 2)
+        if tuple(out.shape) != (M, N):
+            raise _lib.SvlmError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
+        if bias is not None:
+            _req(bias, BF16, "gemm.bias", 1)
+            assert bias.numel() == N
+        ldr = 0
+        if residual is not None:
+            _req(residual, BF16, "gemm.residual", 2)
+            assert tuple(residual.shape) == (M, N)
+            ldr = residual.stride(0)
+        check(self.lib.svlm_gemm_bf16(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual), ldr,
+                                      _ptr(out), out.stride(0), M, N, K, act, _stream()), "svlm_gemm_bf16")
+        return out
+
+    def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=ACT_NONE):
+        _req(x, BF16, "gemv.x"); _req(W, BF16, "gemv.W", 2)
+        N, K = W.shape
+        if x.numel() != K:
+            raise _lib.SvlmError(f"gemv: x has {x.numel()} elements, W is {tuple(W.shape)}")
+        if out is None and out_f32 is None:
+            out = torch.empty((N,), dtype=BF16, device=x.device)
+        if out is not None:
+            _req(out, BF16, "gemv.out"); assert out.numel() == N
+        if out_f32 is not None:
+            _req(out_f32, torch.float32, "gemv.out_f32"); assert out_f32.numel() == N
+        if bias is not None:
+            _req(bias, BF16, "gemv.bias"); assert bias.numel() == N
+        if residual is not None:
+            _req(residual, BF16, "gemv.residual"); assert residual.numel() == N
+        check(self.lib.svlm_gemv_bf16(_ptr(x), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual), _ptr(out), _ptr(out_f32),
+                                      N, K, act, _stream()), "svlm_gemv_bf16")
+        return out if out is not None else out_f32
+
+    def rmsnorm(self, x, w, eps, out=None):
+        _req(x, BF16, "rmsnorm.x"); _req(w, BF16, "rmsnorm.w", 1)
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        assert x.is_contiguous() and w.numel() == cols
+        if out is None:
+            out = torch.empty_like(x)
+        _req(out, BF16, "rmsnorm.out"); assert out.is_contiguous() and out.numel() == x.numel()
+        check(self.lib.svlm_rmsnorm(_ptr(x), _ptr(w), _ptr(out), rows, cols, float(eps), _stream()), "svlm_rmsnorm")
+        return out
+
+    def layernorm(self, x, w, b, eps, out=None):
+        _req(x, BF16, "layernorm.x"); _req(w, BF16, "layernorm.w", 1); _req(b, BF16, "layernorm.b", 1)
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        assert x.is_contiguous() and w.numel() == cols and b.numel() == cols
+        if out is None:
+            out = torch.empty_like(x)
+        _req(out, BF16, "layernorm.out"); assert out.is_contiguous() and out.numel() == x.numel()
+        check(self.lib.svlm_layernorm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), rows, cols, float(eps), _stream()), "svlm_layernorm")
+        return out
+
+    def add(self, a, b, out=None):
+        _req(a, BF16, "add.a"); _req(b, BF16, "add.b")
+        assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+        if out is None:
+            out = torch.empty_like(a)
+        check(self.lib.svlm_add(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()), "svlm_add")
+        return out
+
+    def silu_mul(self, gu, out=None):
+        _req(gu, BF16, "silu_mul.gu", 2)
+        rows, two_i = gu.shape
+        assert gu.is_contiguous() and two_i % 2 == 0
+        if out is None:
+            out = torch.empty((rows, two_i // 2), dtype=BF16, device=gu.device)
+        assert out.is_contiguous() and tuple(out.shape) == (rows, two_i // 2)
+        check(self.lib.svlm_silu_mul(_ptr(gu), _ptr(out), rows, two_i // 2, _stream()), "svlm_silu_mul")
+        return out
+
+    def gather_rows(self, table, alt, idx, out, idx_off=None):
+        _req(table, BF16, "gather.table", 2); _req(idx, torch.int32, "gather.idx", 1); _req(out, BF16, "gather.out", 2)
+        rows, cols = out.shape
+        assert table.is_contiguous() and out.is_contiguous() and table.shape[1] == cols
+        if alt is not None:
+            _req(alt, BF16, "gather.alt", 2); assert alt.is_contiguous() and alt.shape[1] == cols
+        if idx_off is None:
+            assert idx.numel() >= rows
+        else:
+            _req(idx_off, torch.int32, "gather.idx_off")
+        check(self.lib.svlm_gather_rows(_ptr(table), _ptr(alt), _ptr(idx), _ptr(idx_off), _ptr(out), rows, cols, _stream()),
+              "svlm_gather_rows")
+        return out
+
+    # ------------------------------------------------------------------ ViT
+    def vit_rope(self, qkv, cosT, sinT, H, d):
+        _req(qkv, BF16, "vit_rope.qkv", 2); _req(cosT, torch.float32, "vit_rope.cos", 2); _req(sinT, torch.float32, "vit_rope.sin", 2)
+        N = qkv.shape[0]
+        assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * d
+        assert cosT.is_contiguous() and sinT.is_contiguous() and tuple(cosT.shape) == (N, d // 2) == tuple(sinT.shape)
+        check(self.lib.svlm_vit_rope(_ptr(qkv), _ptr(cosT), _ptr(sinT), N, H, d, _stream()), "svlm_vit_rope")
+        return qkv
+
+    def vit_attn(self, qkv, n_seq, seq_len, H, d, scale, out=None):
+        _req(qkv, BF16, "vit_attn.qkv", 2)
+        N = qkv.shape[0]
+        assert qkv.is_contiguous() and qkv.shape[1] == 3 * H * d and N == n_seq * seq_len
+        if out is None:
+            out = torch.empty((N, H * d), dtype=BF16, device=qkv.device)
+        assert out.is_contiguous() and tuple(out.shape) == (N, H * d)
+        check(self.lib.svlm_vit_attn(_ptr(qkv), _ptr(out), n_seq, seq_len, H, d, float(scale), _stream()), "svlm_vit_attn")
+        return out
+
+    # ------------------------------------------------------------------ rope table / KV pool
+    def mrope_table(self, pos3, inv_freq, rope_cs, start, count, sections):
+        """pos3: (3, stride) int32 or float32; rope_cs: (cap, D) bf16."""
+        _req(inv_freq, torch.float32, "mrope.inv_freq", 1); _req(rope_cs, BF16, "mrope.rope_cs", 2)
+        assert pos3.is_cuda and pos3.dim() == 2 and pos3.shape[0] == 3 and pos3.is_contiguous()
+        D = rope_cs.shape[1]
+        assert rope_cs.is_contiguous() and inv_freq.numel() == D // 2
+        assert 0 <= start and start + count <= min(pos3.shape[1], rope_cs.shape[0]), (start, count, pos3.shape, rope_cs.shape)
+        is_f = pos3.dtype == torch.float32
+        assert is_f or pos3.dtype == torch.int32
+        check(self.lib.svlm_mrope_table(0 if is_f else _ptr(pos3), _ptr(pos3) if is_f else 0, pos3.shape[1], _ptr(inv_freq),
+                                        _ptr(rope_cs), start, count, D, sections[0], sections[1], sections[2], _stream()),
+              "svlm_mrope_table")
+
+    @staticmethod
+    def _planes(pool, layer):
+        # pool (layers, 2, Hkv, n_slots, D)
+        return pool[layer, 0], pool[layer, 1]
+
+    def kv_append(self, k_new, v_new, pool, layer, slot_of, start, T, len_dev=None):
+        """k_new/v_new: (T, Hkv*D) row views (may be column slices of the fused qkv buffer)."""
+        _req(pool, BF16, "kv_append.pool", 5); _req(slot_of, torch.int32, "kv_append.slot_of", 1)
+        _req(k_new, BF16, "kv_append.k", 2); _req(v_new, BF16, "kv_append.v", 2)
+        _, _, Hkv, n_slots, D = pool.shape
+        assert pool.is_contiguous() and k_new.shape[0] >= T and k_new.shape[1] == Hkv * D == v_new.shape[1]
+        if len_dev is None:
+            assert 0 <= start and start + T <= slot_of.numel(), (start, T, slot_of.numel())
+        kp, vp = self._planes(pool, layer)
+        check(self.lib.svlm_kv_append(_ptr(k_new), k_new.stride(0), _ptr(v_new), v_new.stride(0), _ptr(kp), _ptr(vp), _ptr(slot_of),
+                                      _ptr(len_dev), start, T, Hkv, D, n_slots, _stream()), "svlm_kv_append")
+
+    def kv_move_rows(self, pool, src, dst):
+        _req(pool, BF16, "kv_move.pool", 5); _req(src, torch.int32, "kv_move.src", 1); _req(dst, torch.int32, "kv_move.dst", 1)
+        Ly, two, Hkv, n_slots, D = pool.shape
+        n = src.numel()
+        assert pool.is_contiguous() and dst.numel() == n
+        check(self.lib.svlm_kv_move_rows(_ptr(pool), Ly * two * Hkv, n_slots, D, _ptr(src), _ptr(dst), n, _stream()), "svlm_kv_move_rows")
+
+    def kv_gather(self, pool, layer, which, slot_of, L):
+        _req(pool, BF16, "kv_gather.pool", 5); _req(slot_of, torch.int32, "kv_gather.slot_of", 1)
+        _, _, Hkv, n_slots, D = pool.shape
+        assert slot_of.numel() >= L
+        out = torch.empty((Hkv, L, D), dtype=BF16, device=pool.device)
+        check(self.lib.svlm_kv_gather(_ptr(pool[layer, which]), _ptr(slot_of), _ptr(out), L, Hkv, D, n_slots, _stream()), "svlm_kv_gather")
+        return out
+
+    # ------------------------------------------------------------------ attention
+    def decode_attn_ws(self, Hq, max_len, chunk, device):
+        nbytes = self.lib.svlm_decode_attn_ws_bytes(Hq, max_len, chunk)
+        if nbytes < 0:
+            raise _lib.SvlmError("svlm_decode_attn_ws_bytes: bad arguments")
+        return torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
+
+    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None):
+        """length = host-known KV length INCLUDING the appended row (len_dev None), or the constant
+        added to *len_dev (normally 1)."""
+        _req(q, BF16, "decode_attn.q"); _req(out, BF16, "decode_attn.out"); _req(ws, torch.float32, "decode_attn.ws", 1)
+        _req(rope_cs, BF16, "decode_attn.rope_cs", 2); _req(slot_of, torch.int32, "decode_attn.slot_of", 1)
+        _, _, Hkv, n_slots, D = pool.shape
+        assert q.numel() == Hq * D == out.numel() and q.is_contiguous() and out.is_contiguous()
+        assert max_len <= slot_of.numel() and max_len <= rope_cs.shape[0] and rope_cs.shape[1] == D
+        need = self.lib.svlm_decode_attn_ws_bytes(Hq, max_len, chunk)
+        assert ws.numel() * 4 >= need, (ws.numel() * 4, need)
+        if len_dev is None:
+            assert 0 < length <= max_len, (length, max_len)
+        kp, vp = self._planes(pool, layer)
+        check(self.lib.svlm_decode_attn_ropeload(_ptr(q), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(rope_cs), _ptr(len_dev), length,
+                                                 _ptr(out), _ptr(ws), Hq, Hkv, D, n_slots, max_len, chunk, float(scale), _stream()),
+              "svlm_decode_attn_ropeload")
+        return out
+
+    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale):
+        _req(q, BF16, "prefill_attn.q", 2); _req(out, BF16, "prefill_attn.out", 2)
+        _req(rope_cs, BF16, "prefill_attn.rope_cs", 2); _req(slot_of, torch.int32, "prefill_attn.slot_of", 1)
+        _, _, Hkv, n_slots, D = pool.shape
+        assert q.shape[0] >= T and q.shape[1] == Hq * D and out.shape[0] >= T and out.shape[1] == Hq * D
+        assert T <= L <= slot_of.numel() and L <= rope_cs.shape[0] and rope_cs.shape[1] == D
+        kp, vp = self._planes(pool, layer)
+        check(self.lib.svlm_prefill_attn_ropeload(_ptr(q), q.stride(0), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(rope_cs), _ptr(out),
+                                                  out.stride(0), T, L, Hq, Hkv, D, n_slots, float(scale), _stream()),
+              "svlm_prefill_attn_ropeload")
+        return out
+
+    # ------------------------------------------------------------------ sampling
+    def mark_seen(self, ids, n, seen):
+        _req(ids, torch.int32, "mark_seen.ids", 1); _req(seen, torch.uint8, "mark_seen.seen", 1)
+        assert ids.numel() >= n
+        check(self.lib.svlm_mark_seen(_ptr(ids), n, _ptr(seen), seen.numel(), _stream()), "svlm_mark_seen")
+
+    def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv):
+        _req(logits, torch.float32, "argmax.logits", 1); _req(tok_buf, torch.int32, "argmax.tok_buf", 1)
+        _req(state, torch.int32, "argmax.state", 1)
+        if seen is not None:
+            _req(seen, torch.uint8, "argmax.seen", 1); assert seen.numel() == logits.numel()
+        n_sup = 0
+        if suppress is not None:
+            _req(suppress, torch.int32, "argmax.suppress", 1)
+            n_sup = suppress.numel()
+        assert state.numel() >= 2
+        check(self.lib.svlm_penalty_argmax(_ptr(logits), logits.numel(), _ptr(seen), float(penalty), _ptr(suppress), n_sup,
+                                           _ptr(tok_buf), _ptr(state), int(advance_kv), _stream()), "svlm_penalty_argmax")

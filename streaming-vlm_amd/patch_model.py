@@ -1,0 +1,79 @@
+"""``convert_qwen2_to_streaming`` -- same entry point as the reference's
+``src/streaming_vlm/inference/qwen2/patch_model.py:18-34``.
+
+The reference rebinds eleven HF methods so that the stock modules call flash-attn; here the model's
+weights are handed to the HIP engine once and ``model.generate`` is rebound to it, keeping the call
+signature the streaming loop uses (inference.py:440-451) and the fields it reads back
+(``.sequences``, ``.past_key_values``; inference.py:456,466).
+"""
+from __future__ import annotations
+
+from types import MethodType, SimpleNamespace
+from typing import Optional
+
+import torch
+
+from .config import ModelConfig, from_hf_config
+from .engine import SvlmEngine
+from .streaming_args import StreamingArgs
+
+
+def _grid_list(g):
+    if g is None:
+        return []
+    return [[int(v) for v in row] for row in (g.tolist() if hasattr(g, "tolist") else g)]
+
+
+def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_videos=None, video_grid_thw=None,
+                       past_key_values=None, max_new_tokens: int = 20, use_cache: bool = True,
+                       return_dict_in_generate: bool = True, do_sample: bool = True, repetition_penalty: float = 1.0,
+                       streaming_args: Optional[StreamingArgs] = None, pad_token_id=None, temperature: float = 1.0,
+                       second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, **unused):
+    """Greedy / sampling generation on the HIP engine (reference: streaming_generate + _sample,
+    generate/streaming_generate_qwen.py:130-278, 8-127)."""
+    eng: SvlmEngine = self._svlm_engine
+    if streaming_args is None:
+        raise ValueError("streaming_args is required (reference: every forward reads streaming_args.pos_mode)")
+    if streaming_args.pos_mode != "shrink":
+        raise NotImplementedError("pos_mode='append' (rotated-K cache, unbounded positions) is not part of the HIP path yet")
+    if input_ids.shape[0] != 1:
+        raise ValueError("the streaming loop is batch-1")
+    ids = input_ids[0].tolist()
+    grids_all = _grid_list(streaming_args.video_grid_thw if streaming_args.video_grid_thw is not None else video_grid_thw)
+    out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
+                       repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator)
+    # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)
+    if streaming_args.input_ids is not None:
+        streaming_args.input_ids = torch.nn.functional.pad(streaming_args.input_ids, (0, out.n_new), "constant", 0)
+    seq = torch.tensor([out.sequences], dtype=torch.long, device=input_ids.device)
+    if not return_dict_in_generate:
+        return seq
+    return SimpleNamespace(sequences=seq, past_key_values=out.past_key_values, logits=out.logits, n_new=out.n_new)
+
+
+class StreamingQwen2VL:
+    """Stand-alone model object (no transformers dependency): config + weights + ``generate``."""
+
+    def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, **engine_kw):
+        self.config = cfg
+        self.device = torch.device(device)
+        self._svlm_engine = SvlmEngine(cfg, state_dict, device, ops=ops, **engine_kw)
+        self.generate = MethodType(streaming_generate, self)
+
+    def new_cache(self):
+        return self._svlm_engine.new_cache()
+
+
+def convert_qwen2_to_streaming(model, ops=None, **engine_kw):
+    """Accepts an HF ``Qwen2VLForConditionalGeneration`` (weights are copied into the engine and
+    ``generate`` is rebound) or an already converted model (returned unchanged)."""
+    if getattr(model, "_svlm_engine", None) is not None:
+        return model
+    cfg = from_hf_config(model.config)
+    device = next(model.parameters()).device
+    sd = {k: v for k, v in model.state_dict().items()}
+    if cfg.text.tie_word_embeddings:
+        sd.pop("lm_head.weight", None)
+    model._svlm_engine = SvlmEngine(cfg, sd, device, ops=ops, **engine_kw)
+    model.generate = MethodType(streaming_generate, model)
+    return model

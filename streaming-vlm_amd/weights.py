@@ -1,0 +1,113 @@
+"""Weight containers: HF state-dict names in, device-resident fused bf16 matrices out.
+
+State-dict keys follow ``Qwen2VLForConditionalGeneration`` (transformers >= 4.52 layout, the one
+the reference patches: ``model.model.language_model`` / ``model.model.visual``,
+qwen2/patch_model.py:24-26), so ``convert_qwen2_to_streaming(hf_model)`` can pass
+``hf_model.state_dict()`` straight in.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .config import ModelConfig
+
+V_PREFIX = "model.visual."
+L_PREFIX = "model.language_model."
+
+
+def state_dict_shapes(cfg: ModelConfig) -> Dict[str, tuple]:
+    vc, tc = cfg.vision, cfg.text
+    E, Hd = vc.embed_dim, tc.hidden_size
+    sh = {V_PREFIX + "patch_embed.proj.weight": (E, vc.in_channels, vc.temporal_patch_size, vc.patch_size, vc.patch_size)}
+    for b in range(vc.depth):
+        p = f"{V_PREFIX}blocks.{b}."
+        sh.update({p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,),
+                   p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
+                   p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,),
+                   p + "mlp.fc1.weight": (vc.mlp_hidden, E), p + "mlp.fc1.bias": (vc.mlp_hidden,),
+                   p + "mlp.fc2.weight": (E, vc.mlp_hidden), p + "mlp.fc2.bias": (E,)})
+    M = E * vc.spatial_merge_size ** 2
+    m = V_PREFIX + "merger."
+    sh.update({m + "ln_q.weight": (E,), m + "ln_q.bias": (E,), m + "mlp.0.weight": (M, M), m + "mlp.0.bias": (M,),
+               m + "mlp.2.weight": (Hd, M), m + "mlp.2.bias": (Hd,)})
+    sh[L_PREFIX + "embed_tokens.weight"] = (tc.vocab_size, Hd)
+    qd, kd = tc.num_heads * tc.head_dim, tc.num_kv_heads * tc.head_dim
+    for i in range(tc.num_layers):
+        p = f"{L_PREFIX}layers.{i}."
+        sh.update({p + "input_layernorm.weight": (Hd,), p + "post_attention_layernorm.weight": (Hd,),
+                   p + "self_attn.q_proj.weight": (qd, Hd), p + "self_attn.q_proj.bias": (qd,),
+                   p + "self_attn.k_proj.weight": (kd, Hd), p + "self_attn.k_proj.bias": (kd,),
+                   p + "self_attn.v_proj.weight": (kd, Hd), p + "self_attn.v_proj.bias": (kd,),
+                   p + "self_attn.o_proj.weight": (Hd, qd),
+                   p + "mlp.gate_proj.weight": (tc.intermediate_size, Hd), p + "mlp.up_proj.weight": (tc.intermediate_size, Hd),
+                   p + "mlp.down_proj.weight": (Hd, tc.intermediate_size)})
+    sh[L_PREFIX + "norm.weight"] = (Hd,)
+    if not tc.tie_word_embeddings:
+        sh["lm_head.weight"] = (tc.vocab_size, Hd)
+    return sh
+
+
+def random_state_dict(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch.bfloat16, std: float = 0.02):
+    """Random-init weights of the real shapes (no checkpoint is available offline): matrices and
+    biases N(0, std), norm gains 1 + N(0, std)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    sd = {}
+    for name, shape in state_dict_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std
+        if name.endswith("norm.weight") or "norm1.weight" in name or "norm2.weight" in name or name.endswith("ln_q.weight") \
+                or name.endswith("layernorm.weight"):
+            t = t + 1.0
+        sd[name] = t.to(dtype)
+    return sd
+
+
+class EngineWeights:
+    """Fused, contiguous, device-resident views the kernels consume."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: ModelConfig, device):
+        vc, tc = cfg.vision, cfg.text
+        want = state_dict_shapes(cfg)
+        missing = [k for k in want if k not in sd]
+        if missing:
+            raise KeyError(f"state dict lacks {len(missing)} tensors, e.g. {missing[:3]}")
+        for k, shp in want.items():
+            if tuple(sd[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != expected {shp}")
+
+        def dev(t):
+            return t.detach().to(device=device, dtype=torch.bfloat16).contiguous()
+
+        self.patch_embed = dev(sd[V_PREFIX + "patch_embed.proj.weight"].reshape(vc.embed_dim, -1))
+        self.vit = []
+        for b in range(vc.depth):
+            p = f"{V_PREFIX}blocks.{b}."
+            self.vit.append({k: dev(sd[p + n]) for k, n in [
+                ("n1w", "norm1.weight"), ("n1b", "norm1.bias"), ("n2w", "norm2.weight"), ("n2b", "norm2.bias"),
+                ("qkv_w", "attn.qkv.weight"), ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"),
+                ("proj_b", "attn.proj.bias"), ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"),
+                ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")]})
+        m = V_PREFIX + "merger."
+        self.merger = {k: dev(sd[m + n]) for k, n in [("ln_w", "ln_q.weight"), ("ln_b", "ln_q.bias"), ("w0", "mlp.0.weight"),
+                                                       ("b0", "mlp.0.bias"), ("w2", "mlp.2.weight"), ("b2", "mlp.2.bias")]}
+        self.embed = dev(sd[L_PREFIX + "embed_tokens.weight"])
+        self.lm_head = self.embed if tc.tie_word_embeddings else dev(sd["lm_head.weight"])
+        self.final_norm = dev(sd[L_PREFIX + "norm.weight"])
+        self.layers = []
+        for i in range(tc.num_layers):
+            p = f"{L_PREFIX}layers.{i}."
+            qkv_w = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0)
+            qkv_b = torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0)
+            gu_w = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
+            self.layers.append(dict(ln1=dev(sd[p + "input_layernorm.weight"]), ln2=dev(sd[p + "post_attention_layernorm.weight"]),
+                                    qkv_w=dev(qkv_w), qkv_b=dev(qkv_b), o_w=dev(sd[p + "self_attn.o_proj.weight"]),
+                                    gu_w=dev(gu_w), down_w=dev(sd[p + "mlp.down_proj.weight"])))
+
+    def nbytes_llm_decode(self) -> int:
+        """Weight bytes one decode step streams (layers + final norm + lm_head)."""
+        n = self.lm_head.numel() + self.final_norm.numel()
+        for l in self.layers:
+            n += sum(t.numel() for t in l.values())
+        return n * 2

@@ -1,0 +1,57 @@
+"""Shared test helpers: config bridging between the product and the oracle, chunk sources."""
+from __future__ import annotations
+
+import torch
+
+from oracle import generate as og
+from oracle import model as om
+
+import streaming_vlm_amd as S
+from streaming_vlm_amd import config as C
+
+_V_KEYS = ["depth", "embed_dim", "num_heads", "mlp_hidden", "patch_size", "temporal_patch_size", "spatial_merge_size", "in_channels"]
+_T_KEYS = ["hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim", "intermediate_size", "vocab_size", "rms_eps",
+           "rope_theta", "mrope_section", "tie_word_embeddings"]
+
+
+def oracle_cfg(cfg: C.ModelConfig) -> om.ModelCfg:
+    return om.ModelCfg(om.VisionCfg(**{k: getattr(cfg.vision, k) for k in _V_KEYS}),
+                       om.TextCfg(**{k: getattr(cfg.text, k) for k in _T_KEYS}),
+                       video_token_id=cfg.video_token_id, vision_start_token_id=cfg.vision_start_token_id)
+
+
+def chunk_source(proc, video, previous_text="", query="Commentate on this match", chunk_duration=1, skip_first_chunk=0):
+    """Per-chunk (ids, pixel_values, grid) exactly as streaming_inference builds them (inference.py:351-395)."""
+    def src(i):
+        start = (i + skip_first_chunk) * chunk_duration
+        prompt = f"Time={start:.1f}-{start + chunk_duration:.1f}s"
+        frames = video.chunk(start, chunk_duration)
+        if i == 0:
+            conv = [{"role": "previous text", "content": previous_text},
+                    {"role": "user", "content": [{"type": "text", "text": prompt}, {"type": "video", "video": ""},
+                                                 {"type": "text", "text": query}]}]
+            text = proc.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)
+        else:
+            conv = [{"role": "user", "content": [{"type": "text", "text": prompt}, {"type": "video", "video": ""}]}]
+            text = "\n" + proc.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)[S.SYSTEM_PROMPT_OFFSET:]
+        out = proc(text=[text], videos=frames, return_tensors="pt")
+        return out["input_ids"][0].tolist(), out["pixel_values_videos"], out["video_grid_thw"].tolist()
+    return src
+
+
+def run_oracle_stream(cfg, sd, n_chunks, size=56, fps=1.0, policy="sink_window", sink=4, window=64, max_new=8, suppress_eos=True,
+                      previous_text="hello world", keep_logits=False, **policy_kw):
+    proc = S.SyntheticProcessor()
+    video = S.SyntheticVideo(size, fps, 0)
+    scfg = og.StreamCfg(policy=policy, sink=sink, window=window, max_new_tokens=max_new, suppress_eos=suppress_eos, **policy_kw)
+    return og.streaming_loop(sd, oracle_cfg(cfg), scfg, n_chunks, chunk_source(proc, video, previous_text), keep_logits=keep_logits)
+
+
+def run_engine_stream(model, n_chunks, size=56, fps=1.0, policy="sink_window", sink=4, window=64, max_new=8, suppress_eos=True,
+                      previous_text="hello world", **kw):
+    trace, counts, ids_log = [], [], []
+    res = S.streaming_inference(model=model, processor=S.SyntheticProcessor(), video_path=f"synthetic://{size}x{size}@{fps:g}fps",
+                                model_base="Qwen2", duration=n_chunks, previous_text=previous_text, kv_policy=policy, sink=sink,
+                                window=window, do_sample=False, max_new_tokens=max_new, suppress_eos=suppress_eos, quiet=True,
+                                trace=trace, token_counts=counts, ids_log=ids_log, **kw)
+    return res, trace, counts, ids_log

@@ -1,0 +1,185 @@
+"""TEST-ONLY ops backend: the ``ops.HipOps`` interface implemented with eager CPU torch (oracle math).
+
+It exists so that the HOST logic of the product (KV pool / slot table, eviction policies, position
+ids, prompt building, generate loop, device-state feedback) can be exercised on a machine without a
+GPU.  It is never importable from the product package; the product has no CPU path.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import model as om
+
+BF16 = torch.bfloat16
+
+
+def _act(y, act):
+    if act == 1:
+        return om.quick_gelu(y)
+    if act == 2:
+        return F.gelu(y)
+    if act == 3:
+        return F.silu(y)
+    return y
+
+
+class RefOps:
+    name = "ref-cpu"
+
+    def gemm(self, A, W, bias=None, residual=None, out=None, act=0):
+        y = _act(F.linear(A, W, bias), act)
+        if residual is not None:
+            y = residual + y
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+    def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=0):
+        y = _act(F.linear(x.reshape(1, -1), W, bias)[0], act)
+        if residual is not None:
+            y = residual.reshape(-1) + y
+        if out is not None:
+            out.reshape(-1).copy_(y)
+        if out_f32 is not None:
+            out_f32.copy_(y.float())
+        return out if out is not None else out_f32
+
+    def rmsnorm(self, x, w, eps, out=None):
+        y = om.rms_norm(x, w, eps)
+        if out is None:
+            return y
+        out.copy_(y.reshape(out.shape))
+        return out
+
+    def layernorm(self, x, w, b, eps, out=None):
+        y = F.layer_norm(x, (x.shape[-1],), w, b, eps)
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+    def add(self, a, b, out=None):
+        y = a + b
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+    def silu_mul(self, gu, out=None):
+        I = gu.shape[1] // 2
+        y = F.silu(gu[:, :I]) * gu[:, I:]
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+    def gather_rows(self, table, alt, idx, out, idx_off=None):
+        off = int(idx_off[0]) if idx_off is not None else 0
+        rows = out.shape[0]
+        for r in range(rows):
+            i = int(idx[off + r])
+            out[r] = table[i] if i >= 0 else alt[-1 - i]
+        return out
+
+    def vit_rope(self, qkv, cosT, sinT, H, d):
+        N = qkv.shape[0]
+        v = qkv.view(N, 3, H, d)
+        cos = torch.cat([cosT, cosT], -1).unsqueeze(1)
+        sin = torch.cat([sinT, sinT], -1).unsqueeze(1)
+        for which in (0, 1):
+            x = v[:, which].float()
+            v[:, which] = (x * cos + om.rotate_half(x) * sin).to(qkv.dtype)
+        return qkv
+
+    def vit_attn(self, qkv, n_seq, seq_len, H, d, scale, out=None):
+        N = qkv.shape[0]
+        v = qkv.view(N, 3, H, d)
+        res = torch.empty((N, H * d), dtype=qkv.dtype)
+        for s in range(n_seq):
+            sl = slice(s * seq_len, (s + 1) * seq_len)
+            q, k, vv = (v[sl, j].transpose(0, 1) for j in range(3))
+            res[sl] = om.flash_attention(q, k, vv, None, scale).transpose(0, 1).reshape(seq_len, H * d)
+        if out is None:
+            return res
+        out.copy_(res)
+        return out
+
+    def mrope_table(self, pos3, inv_freq, rope_cs, start, count, sections):
+        D = rope_cs.shape[1]
+        half = D // 2
+        p = pos3[:, start:start + count].float()
+        axis = torch.tensor([0] * sections[0] + [1] * sections[1] + [2] * sections[2])
+        ang = p[axis, :].t() * inv_freq.unsqueeze(0)          # (count, half)
+        rope_cs[start:start + count, :half] = ang.cos().to(BF16)
+        rope_cs[start:start + count, half:] = ang.sin().to(BF16)
+
+    def kv_append(self, k_new, v_new, pool, layer, slot_of, start, T, len_dev=None):
+        base = int(len_dev[0]) if len_dev is not None else start
+        _, _, Hkv, n_slots, D = pool.shape
+        for t in range(T):
+            s = int(slot_of[base + t])
+            pool[layer, 0, :, s] = k_new[t].view(Hkv, D)
+            pool[layer, 1, :, s] = v_new[t].view(Hkv, D)
+
+    def kv_move_rows(self, pool, src, dst):
+        pool[:, :, :, dst.long()] = pool[:, :, :, src.long()]
+
+    def kv_gather(self, pool, layer, which, slot_of, L):
+        return pool[layer, which][:, slot_of[:L].long()].contiguous()
+
+    def decode_attn_ws(self, Hq, max_len, chunk, device):
+        return torch.zeros(1, dtype=torch.float32)
+
+    def _rot(self, x, rope_cs, rows):
+        """x (H, n, D) un-rotated, rope rows (n,) -> eager bf16 rope (x*cos + rotate_half(x)*sin)."""
+        half = rope_cs.shape[1] // 2
+        cs = rope_cs[rows]
+        cos = torch.cat([cs[:, :half], cs[:, :half]], -1)
+        sin = torch.cat([cs[:, half:], cs[:, half:]], -1)
+        return om.apply_rope(x, cos, sin)
+
+    def _attend(self, q, pool, layer, slot_of, rope_cs, T, L, Hq, scale):
+        _, _, Hkv, n_slots, D = pool.shape
+        sl = slot_of[:L].long()
+        K = pool[layer, 0][:, sl]
+        V = pool[layer, 1][:, sl]
+        rows = torch.arange(L)
+        Kr = self._rot(K, rope_cs, rows).repeat_interleave(Hq // Hkv, dim=0)
+        Vr = V.repeat_interleave(Hq // Hkv, dim=0)
+        qr = self._rot(q, rope_cs, rows[L - T:])
+        return om.flash_attention(qr, Kr, Vr, L - T, scale)
+
+    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None):
+        L = (int(len_dev[0]) if len_dev is not None else 0) + length
+        D = pool.shape[-1]
+        o = self._attend(q.view(Hq, 1, D), pool, layer, slot_of, rope_cs, 1, L, Hq, scale)
+        out.copy_(o.reshape(out.shape))
+        return out
+
+    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale):
+        D = pool.shape[-1]
+        o = self._attend(q[:T].reshape(T, Hq, D).transpose(0, 1), pool, layer, slot_of, rope_cs, T, L, Hq, scale)
+        out[:T] = o.transpose(0, 1).reshape(T, Hq * D)
+        return out
+
+    def mark_seen(self, ids, n, seen):
+        seen[ids[:n].long()] = 1
+
+    def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv):
+        sc = logits.clone()
+        if seen is not None:
+            m = seen.bool()
+            sc[m] = torch.where(sc[m] < 0, sc[m] * penalty, sc[m] / penalty)
+        if suppress is not None:
+            sc[suppress.long()] = float("-inf")
+        tok = int(torch.argmax(sc))
+        cur = int(state[1]) + 1
+        tok_buf[cur] = tok
+        state[1] = cur
+        state[0] += advance_kv
+        if seen is not None:
+            seen[tok] = 1

@@ -1,0 +1,285 @@
+"""GPU parity: every C-ABI kernel against the CPU oracle math (tests/ref_ops.py) on seeded inputs.
+
+Tolerances (stated per test): outputs are bf16, so the bar is "same value up to one bf16 rounding
+flip": max |err| <= 2^-7 * max|ref| (one ulp at the top of the range) AND mean |err| <= 1e-3 * max|ref|
+(a systematic error of even a tenth of an ulp fails the mean).  Integer / index outputs are exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from streaming_vlm_amd.ops import HipOps
+    return HipOps()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from ref_ops import RefOps
+    return RefOps()
+
+
+def rnd(shape, seed, scale=1.0, dtype=BF16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    scale = float(want.abs().max()) + 1e-30
+    err = (got - want).abs()
+    mx, mean = float(err.max()) / scale, float(err.mean()) / scale
+    frac = float((err > 0).float().mean())
+    print(f"[{name}] max_err/scale={mx:.3e} mean_err/scale={mean:.3e} mismatched={frac:.4f} scale={scale:.3e}")
+    assert mx <= max_tol, f"{name}: max err {mx:.3e} > {max_tol:.3e}"
+    assert mean <= mean_tol, f"{name}: mean err {mean:.3e} > {mean_tol:.3e}"
+
+
+# ----------------------------------------------------------------------------- GEMM / GEMV
+@pytest.mark.parametrize("M,N,K,bias,res,act", [
+    (1024, 3840, 1280, True, False, 0),     # ViT qkv
+    (1024, 1280, 1176, False, False, 0),    # patch embed (K not a multiple of 64)
+    (1024, 5120, 1280, True, False, 1),     # fc1 + quick_gelu
+    (1024, 1280, 5120, True, True, 0),      # fc2 + residual
+    (256, 5120, 5120, True, False, 2),      # merger + gelu
+    (275, 2048, 1536, True, False, 0),      # 2B prefill qkv (ragged M)
+    (275, 17920, 1536, False, False, 0),    # 2B gate_up
+    (275, 1536, 8960, False, True, 0),      # 2B down + residual
+    (70, 512, 256, True, True, 3),          # tiny, silu
+    (1, 36, 8, True, False, 0),             # degenerate
+    (129, 132, 72, False, False, 0),        # ragged everything
+])
+def test_gemm(ops, ref, M, N, K, bias, res, act):
+    A, W = rnd((M, K), 1), rnd((N, K), 2, 0.05)
+    b = rnd((N,), 3, 0.1) if bias else None
+    r = rnd((M, N), 4) if res else None
+    want = ref.gemm(A, W, b, r, act=act)
+    got = ops.gemm(A.cuda(), W.cuda(), b.cuda() if bias else None, r.cuda() if res else None, act=act)
+    close(f"gemm {M}x{N}x{K} act{act}", got, want)
+
+
+def test_gemm_inplace_residual(ops, ref):
+    A, W, x = rnd((300, 256), 1), rnd((512, 256), 2, 0.05), rnd((300, 512), 3)
+    want = ref.gemm(A, W, None, x)
+    xg = x.cuda()
+    ops.gemm(A.cuda(), W.cuda(), residual=xg, out=xg)
+    close("gemm in-place residual", xg, want)
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    from streaming_vlm_amd._lib import SvlmError
+    with pytest.raises(SvlmError):
+        ops.gemm(rnd((4, 12), 1).cuda(), rnd((8, 12), 2).cuda())         # K % 8 != 0
+    with pytest.raises(SvlmError):
+        ops.gemm(rnd((4, 16), 1), rnd((8, 16), 2))                          # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("N,K,bias,res,f32", [
+    (2048, 1536, True, False, False), (1536, 1536, False, True, False), (17920, 1536, False, False, False),
+    (1536, 8960, False, True, False), (151936, 1536, False, False, True), (520, 264, True, True, False), (7, 8, False, False, True),
+])
+def test_gemv(ops, ref, N, K, bias, res, f32):
+    x, W = rnd((K,), 1), rnd((N, K), 2, 0.05)
+    b = rnd((N,), 3, 0.1) if bias else None
+    r = rnd((N,), 4) if res else None
+    want = ref.gemv(x, W, b, r, out=torch.empty(N, dtype=BF16))
+    if f32:
+        out = torch.empty(N, dtype=torch.float32, device="cuda")
+        ops.gemv(x.cuda(), W.cuda(), b.cuda() if bias else None, r.cuda() if res else None, out_f32=out)
+        assert torch.equal(out.cpu(), out.cpu().to(BF16).float()), "fp32 logits must be bf16-representable"
+    else:
+        out = ops.gemv(x.cuda(), W.cuda(), b.cuda() if bias else None, r.cuda() if res else None)
+    close(f"gemv {N}x{K}", out, want)
+
+
+# ----------------------------------------------------------------------------- norms / elementwise
+@pytest.mark.parametrize("rows,cols", [(1, 1536), (275, 1536), (3, 3584), (5, 256), (1024, 1280)])
+def test_rmsnorm_layernorm(ops, ref, rows, cols):
+    x, w, b = rnd((rows, cols), 1, 3.0), rnd((cols,), 2) + 1, rnd((cols,), 3, 0.1)
+    close("rmsnorm", ops.rmsnorm(x.cuda(), w.cuda(), 1e-6), ref.rmsnorm(x, w, 1e-6))
+    close("layernorm", ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-6), ref.layernorm(x, w, b, 1e-6))
+
+
+def test_add_silu_gather(ops, ref):
+    a, b = rnd((33, 256), 1), rnd((33, 256), 2)
+    close("add", ops.add(a.cuda(), b.cuda()), a + b, max_tol=0, mean_tol=0)
+    gu = rnd((17, 1024), 3, 2.0)
+    close("silu_mul", ops.silu_mul(gu.cuda()), ref.silu_mul(gu))
+    table, alt = rnd((100, 64), 4), rnd((10, 64), 5)
+    idx = torch.tensor([5, -1, 99, -10, 0, 7], dtype=torch.int32)
+    out = torch.empty((6, 64), dtype=BF16, device="cuda")
+    ops.gather_rows(table.cuda(), alt.cuda(), idx.cuda(), out)
+    want = ref.gather_rows(table, alt, idx, torch.empty((6, 64), dtype=BF16))
+    assert torch.equal(out.cpu(), want)
+    off = torch.tensor([2], dtype=torch.int32, device="cuda")
+    out1 = torch.empty((1, 64), dtype=BF16, device="cuda")
+    ops.gather_rows(table.cuda(), None, idx.cuda(), out1, idx_off=off)
+    assert torch.equal(out1.cpu()[0], table[99])
+
+
+# ----------------------------------------------------------------------------- ViT attention
+@pytest.mark.parametrize("n_seq,seq_len,H,d", [(1, 1024, 16, 80), (2, 256, 16, 80), (1, 64, 2, 80), (3, 16, 2, 80), (1, 100, 4, 128)])
+def test_vit_rope_attn(ops, ref, n_seq, seq_len, H, d):
+    N = n_seq * seq_len
+    qkv = rnd((N, 3 * H * d), 1)
+    ang = torch.rand((N, d // 2), generator=torch.Generator().manual_seed(2)) * 30
+    cosT, sinT = ang.cos().contiguous(), ang.sin().contiguous()
+    want_q = ref.vit_rope(qkv.clone(), cosT, sinT, H, d)
+    got_q = ops.vit_rope(qkv.cuda(), cosT.cuda(), sinT.cuda(), H, d)
+    close("vit_rope", got_q, want_q)
+    scale = 1 / math.sqrt(d)
+    # feed BOTH attention implementations the same rotated buffer
+    want = ref.vit_attn(want_q, n_seq, seq_len, H, d, scale)
+    got = ops.vit_attn(want_q.cuda(), n_seq, seq_len, H, d, scale)
+    close(f"vit_attn {n_seq}x{seq_len} H{H} d{d}", got, want, max_tol=2 ** -6, mean_tol=1e-3)
+
+
+# ----------------------------------------------------------------------------- rope table / KV pool
+def test_mrope_table(ops, ref):
+    L, D = 300, 128
+    g = torch.Generator().manual_seed(0)
+    pos3 = torch.randint(0, 5000, (3, 512), generator=g, dtype=torch.int32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    want = torch.zeros((512, D), dtype=BF16)
+    ref.mrope_table(pos3, inv, want, 7, L, [16, 24, 24])
+    got = torch.zeros((512, D), dtype=BF16, device="cuda")
+    ops.mrope_table(pos3.cuda(), inv.cuda(), got, 7, L, [16, 24, 24])
+    diff = (got.cpu().float() - want.float()).abs()
+    print(f"[mrope_table] max diff {float(diff.max()):.3e} mismatched {float((diff > 0).float().mean()):.5f}")
+    assert float(diff.max()) <= 2 ** -7        # one bf16 ulp at |x|<=1 (libm vs ocml last-bit differences)
+    assert float((diff > 0).float().mean()) < 0.02
+    assert torch.equal(got.cpu()[:7], torch.zeros((7, D), dtype=BF16))    # rows outside [start, start+count) untouched
+
+
+def _pool(layers=2, Hkv=2, n_slots=96, D=128, seed=0):
+    return rnd((layers, 2, Hkv, n_slots, D), seed)
+
+
+def test_kv_append_gather_move(ops, ref):
+    pool_c = _pool()
+    pool_g = pool_c.clone().cuda()
+    Hkv, D, n_slots = 2, 128, 96
+    perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    slot_of = perm[:64].clone()
+    T = 9
+    qkv = rnd((T, 3 * Hkv * D), 2)
+    k_new, v_new = qkv[:, Hkv * D:2 * Hkv * D], qkv[:, 2 * Hkv * D:]
+    qkv_g = qkv.cuda()
+    ref.kv_append(k_new, v_new, pool_c, 1, slot_of, 20, T)
+    ops.kv_append(qkv_g[:, Hkv * D:2 * Hkv * D], qkv_g[:, 2 * Hkv * D:], pool_g, 1, slot_of.cuda(), 20, T)
+    assert torch.equal(pool_g.cpu(), pool_c), "kv_append (host start)"
+    len_dev = torch.tensor([31], dtype=torch.int32, device="cuda")
+    ref.kv_append(k_new[:1], v_new[:1], pool_c, 0, slot_of, 31, 1)
+    ops.kv_append(qkv_g[:1, Hkv * D:2 * Hkv * D], qkv_g[:1, 2 * Hkv * D:], pool_g, 0, slot_of.cuda(), 0, 1, len_dev=len_dev)
+    assert torch.equal(pool_g.cpu(), pool_c), "kv_append (device length)"
+    for which in (0, 1):
+        assert torch.equal(ops.kv_gather(pool_g, 1, which, slot_of.cuda(), 40).cpu(), ref.kv_gather(pool_c, 1, which, slot_of, 40))
+    src, dst = perm[:10].clone(), perm[64:74].clone()
+    ref.kv_move_rows(pool_c, src, dst)
+    ops.kv_move_rows(pool_g, src.cuda(), dst.cuda())
+    assert torch.equal(pool_g.cpu(), pool_c), "kv_move_rows"
+
+
+# ----------------------------------------------------------------------------- LLM attention
+def _attn_setup(Hq, Hkv, L, cap, seed):
+    D = 128
+    n_slots = cap + 32
+    pool = rnd((1, 2, Hkv, n_slots, D), seed)
+    perm = torch.randperm(n_slots, generator=torch.Generator().manual_seed(seed + 1)).to(torch.int32)
+    slot_of = perm[:cap].clone().contiguous()
+    pos3 = torch.randint(0, 3000, (3, cap), generator=torch.Generator().manual_seed(seed + 2), dtype=torch.int32)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))
+    rope = torch.zeros((cap, D), dtype=BF16)
+    from ref_ops import RefOps
+    RefOps().mrope_table(pos3, inv, rope, 0, cap, [16, 24, 24])
+    return pool, slot_of, rope
+
+
+@pytest.mark.parametrize("Hq,Hkv,L,chunk", [(12, 2, 2352, 64), (28, 4, 4400, 128), (4, 2, 1, 16), (4, 2, 17, 16), (12, 2, 100, 32),
+                                            (8, 1, 333, 48), (12, 2, 2052, 16)])
+def test_decode_attn(ops, ref, Hq, Hkv, L, chunk):
+    cap = ((L + 63) // 64) * 64 + 64
+    pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 10)
+    q = rnd((Hq * 128,), 3)
+    scale = 1 / math.sqrt(128)
+    want = ref.decode_attn(q, pool, 0, slot_of, rope, torch.empty(Hq * 128, dtype=BF16), None, Hq, cap, chunk, scale, length=L)
+    ws = ops.decode_attn_ws(Hq, cap, chunk, "cuda")
+    out = torch.empty(Hq * 128, dtype=BF16, device="cuda")
+    pg, sg, rg = pool.cuda(), slot_of.cuda(), rope.cuda()
+    ops.decode_attn(q.cuda(), pg, 0, sg, rg, out, ws, Hq, cap, chunk, scale, length=L)
+    close(f"decode_attn Hq{Hq} Hkv{Hkv} L{L} chunk{chunk}", out, want, max_tol=2 ** -6, mean_tol=1e-3)
+    # device-resident length (graph replay path): *len_dev + 1
+    len_dev = torch.tensor([L - 1], dtype=torch.int32, device="cuda")
+    out2 = torch.empty_like(out)
+    ops.decode_attn(q.cuda(), pg, 0, sg, rg, out2, ws, Hq, cap, chunk, scale, length=1, len_dev=len_dev)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("Hq,Hkv,T,L", [(12, 2, 275, 2330), (28, 4, 40, 300), (4, 2, 1, 1), (4, 2, 20, 20), (4, 2, 37, 100), (6, 1, 16, 48)])
+def test_prefill_attn(ops, ref, Hq, Hkv, T, L):
+    cap = ((L + 63) // 64) * 64
+    pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 20)
+    q = rnd((T, Hq * 128), 5)
+    scale = 1 / math.sqrt(128)
+    want = ref.prefill_attn(q, pool, 0, slot_of, rope, torch.empty((T, Hq * 128), dtype=BF16), T, L, Hq, scale)
+    out = torch.empty((T, Hq * 128), dtype=BF16, device="cuda")
+    ops.prefill_attn(q.cuda(), pool.cuda(), 0, slot_of.cuda(), rope.cuda(), out, T, L, Hq, scale)
+    close(f"prefill_attn Hq{Hq} Hkv{Hkv} T{T} L{L}", out, want, max_tol=2 ** -6, mean_tol=1e-3)
+
+
+def test_prefill_matches_decode_on_last_row(ops):
+    """Size-independent property: the last prefill row equals a decode step over the same cache."""
+    Hq, Hkv, T, L = 12, 2, 64, 1500
+    cap = 1536
+    pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 30)
+    q = rnd((T, Hq * 128), 6).cuda()
+    scale = 1 / math.sqrt(128)
+    out = torch.empty((T, Hq * 128), dtype=BF16, device="cuda")
+    pg, sg, rg = pool.cuda(), slot_of.cuda(), rope.cuda()
+    ops.prefill_attn(q, pg, 0, sg, rg, out, T, L, Hq, scale)
+    ws = ops.decode_attn_ws(Hq, cap, 64, "cuda")
+    o1 = torch.empty(Hq * 128, dtype=BF16, device="cuda")
+    ops.decode_attn(q[T - 1].contiguous(), pg, 0, sg, rg, o1, ws, Hq, cap, 64, scale, length=L)
+    close("prefill last row vs decode", out[T - 1], o1, max_tol=2 ** -6, mean_tol=1e-3)
+
+
+# ----------------------------------------------------------------------------- sampling
+def test_penalty_argmax(ops, ref):
+    V = 151936
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(V, generator=g)
+    logits = logits.to(BF16).float()
+    ids = torch.randint(0, V, (500,), generator=g, dtype=torch.int32)
+    top = int(torch.argmax(logits))
+    ids[0] = top                                    # the raw winner is penalised
+    for suppress in (None, torch.tensor([151645, 151643], dtype=torch.int32)):
+        seen_c = torch.zeros(V, dtype=torch.uint8)
+        ref.mark_seen(ids, 500, seen_c)
+        seen_g = torch.zeros(V, dtype=torch.uint8, device="cuda")
+        ops.mark_seen(ids.cuda(), 500, seen_g)
+        assert torch.equal(seen_g.cpu(), seen_c)
+        tb_c, st_c = torch.zeros(8, dtype=torch.int32), torch.tensor([100, -1], dtype=torch.int32)
+        tb_g, st_g = tb_c.clone().cuda(), st_c.clone().cuda()
+        lg = logits.clone()
+        if suppress is not None:
+            lg[151645] = 100.0
+        for adv in (0, 1, 1):
+            ref.penalty_argmax(lg, seen_c, 1.05, suppress, tb_c, st_c, adv)
+            ops.penalty_argmax(lg.cuda(), seen_g, 1.05, suppress.cuda() if suppress is not None else None, tb_g, st_g, adv)
+        assert torch.equal(tb_g.cpu(), tb_c) and torch.equal(st_g.cpu(), st_c) and torch.equal(seen_g.cpu(), seen_c)
+    # ties resolve to the lowest index like torch.argmax
+    flat = torch.zeros(V)
+    tb, st = torch.zeros(4, dtype=torch.int32, device="cuda"), torch.tensor([0, -1], dtype=torch.int32, device="cuda")
+    ops.penalty_argmax(flat.cuda(), None, 1.0, None, tb, st, 0)
+    assert int(tb[0]) == 0
