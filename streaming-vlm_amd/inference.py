@@ -180,7 +180,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         emit_json=False, time_test=False, *, kv_policy="structural", sink=4, window=2048, do_sample=True,
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
-                        generator=None, keep_logits=False):
+                        generator=None, keep_logits=False, chunk_callback=None):
     def _sync():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -237,6 +237,8 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
     printq(f"num_chunks: {num_chunks}", quiet=quiet)
 
     for i in range(num_chunks):
+        if chunk_callback is not None:
+            chunk_callback(i)
         _sync()
         loop_start = time.perf_counter()
         section_time = {k: 0.0 for k in ["PKV", "CHECK", "VIDEO", "INPUT", "GEN", "POST"]}

@@ -173,3 +173,43 @@ class SyntheticProcessor:
     def batch_decode(self, ids, skip_special_tokens: bool = True):
         rows = ids.tolist() if hasattr(ids, "tolist") else ids
         return [self.tokenizer.decode(r, skip_special_tokens) for r in rows]
+
+
+# ----------------------------------------------------------------------------- HBM-resident stream (benchmarks)
+class ResidentChunk:
+    """Handle to one chunk whose patches already live on the device."""
+
+    def __init__(self, pixel_values, grid):
+        self.pixel_values, self.grid = pixel_values, grid
+
+
+class ResidentVideo:
+    """Pre-patchified synthetic stream: `chunk()` hands out device-resident patch tensors so that a timed
+    region starts with its inputs in HBM (bench.py)."""
+
+    def __init__(self, n_chunks: int, size: int, fps: float, stream: int, device, chunk_duration: float = 1.0,
+                 patch: int = 14, temporal: int = 2, merge: int = 2):
+        src = SyntheticVideo(size, fps, stream)
+        self.chunk_duration = chunk_duration
+        self.frames_per_chunk = max(1, int(round(chunk_duration * fps)))
+        self.chunks = []
+        for i in range(n_chunks):
+            pix, grid = patchify(src.chunk(i * chunk_duration, chunk_duration), patch, temporal, merge)
+            self.chunks.append(ResidentChunk(pix.to(device), grid))
+
+    def chunk(self, start_s: float, duration_s: float) -> ResidentChunk:
+        return self.chunks[int(round(start_s / self.chunk_duration))]
+
+
+class ResidentProcessor(SyntheticProcessor):
+    """SyntheticProcessor that accepts `ResidentChunk` handles for `videos=`."""
+
+    def __call__(self, text=None, videos=None, padding=True, return_tensors="pt", **kw):
+        if not isinstance(videos, ResidentChunk):
+            return super().__call__(text=text, videos=videos, padding=padding, return_tensors=return_tensors, **kw)
+        t = (text if isinstance(text, str) else text[0])
+        g = videos.grid[0]
+        t = t.replace("<|video_pad|>", "<|video_pad|>" * (g[0] * g[1] * g[2] // self.merge ** 2))
+        ids = torch.tensor([self.tokenizer.encode(t)], dtype=torch.long)
+        return _Batch(input_ids=ids, attention_mask=torch.ones_like(ids), pixel_values_videos=videos.pixel_values,
+                      video_grid_thw=torch.tensor(videos.grid, dtype=torch.long))
