@@ -59,6 +59,23 @@ class TimedOps:
         nb = 2 * (N * K + K + N * (2 if residual is not None else 1)) + (4 * N if out_f32 is not None else 0)
         return self._run("gemv_bf16_kernel", nb, 2.0 * N * K, self._ops.gemv, x, W, bias, residual, out, out_f32, act)
 
+    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
+        N, K = W.shape
+        return self._run("dec_qkv_kernel", 2 * (N * K + 2 * K + 2 * N), 2.0 * N * K, self._ops.dec_qkv, x, ln_w, eps, W, bias, q_out,
+                         pool, layer, slot_of, qd, kd, length, len_dev)
+
+    def dec_gate_up(self, x, ln_w, eps, W, h):
+        N, K = W.shape
+        return self._run("dec_gate_up_kernel", 2 * (N * K + 2 * K + N // 2), 2.0 * N * K, self._ops.dec_gate_up, x, ln_w, eps, W, h)
+
+    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws):
+        N, K = W.shape
+        return self._run("dec_lm_head_kernel", 2 * (N * K + 2 * K) + 5 * N, 2.0 * N * K, self._ops.dec_lm_head, x, ln_w, eps, W, logits,
+                         seen, penalty, suppress, ws)
+
+    def sampling_ws(self, *a, **k):
+        return self._ops.sampling_ws(*a, **k)
+
     def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None):
         _, _, Hkv, _, D = pool.shape
         L = (int(len_dev[0]) if len_dev is not None else 0) + length     # host read: instrumented pass only
@@ -94,6 +111,14 @@ class TimedOps:
             a["bytes"] += nb
             a["flops"] += fl
         return agg
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the one JSON line)"""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -134,8 +159,10 @@ def main():
     tok_per_frame = (args.size // 28) ** 2
     chunk_tokens = tok_per_frame + 24 + args.new_tokens
     max_len = args.sink + args.window + 2 * chunk_tokens + 64
+    log(f"rank {rank}/{world}: building {cfg.name} random weights on {dev}")
     sd = random_state_dict(cfg, 0, dev)
     model = S.StreamingQwen2VL(cfg, sd, dev, max_len=max_len, max_new_tokens=args.new_tokens)
+    log("engine ready; staging the synthetic stream in HBM")
     video = ResidentVideo(n_chunks + 1, args.size, args.fps, rank, dev)          # inputs resident in HBM before timing
     proc = ResidentProcessor()
     frames_per_chunk = video.frames_per_chunk
@@ -150,8 +177,11 @@ def main():
         torch.cuda.synchronize()
 
     def on_chunk(i):
+        if i == 0:
+            log("stream started (warmup)")
         if i == args.warmup:
             fence()
+            log("timed region starts")
             t["t0"] = time.perf_counter()
 
     S.streaming_inference(model=model, processor=proc, video=video, model_base="Qwen2", duration=n_chunks, previous_text="",
@@ -159,6 +189,7 @@ def main():
                           max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk)
     fence()
     elapsed = time.perf_counter() - t["t0"]
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} chunks")
     frames = args.steps * frames_per_chunk
     tokens = sum(counts[args.warmup:])
     stats = torch.tensor([frames, tokens, elapsed], dtype=torch.float64, device=dev)
@@ -186,8 +217,10 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
+        log("roofline pass (eager launches bracketed by HIP events)")
         out.update(roofline_pass(model, proc, video, args, n_chunks))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores)")
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args)
     if dist is not None:
         dist.barrier()
@@ -260,7 +293,8 @@ def cpu_baseline(cfg, sd, args):
     box's host cores, on a bounded sample of the SAME stream."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
-    cores = os.cpu_count() or 1
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, int(os.environ.get("SVLM_CPU_THREADS", "16"))))     # a 1-GPU box owns a 16-core share
     torch.set_num_threads(cores)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
     n = max(1, args.cpu_chunks)

@@ -111,8 +111,26 @@ int svlm_mark_seen(const int* ids, int n, void* seen, int V, void* stream);
 /* Repetition penalty + argmax (lowest index on ties) + device-side token feedback:
  * tok_buf[state[1]+1] = token; state[1] += 1; state[0] += advance_kv; seen[token] = 1.
  * replaces: logits processors + argmax + cat (generate/streaming_generate_qwen.py:75,99,104). */
+long long svlm_argmax_ws_bytes(void);
 int svlm_penalty_argmax(const float* logits, int V, void* seen, float penalty, const int* suppress, int n_suppress, int* tok_buf,
-                        int* state, int advance_kv, void* stream);
+                        int* state, int advance_kv, void* ws, void* stream);
+
+/* ---- fused decode-step (T = 1) kernels: the per-layer small ops folded into the weight-streaming GEMVs ---- */
+/* RMSNorm(x; ln_w) -> W x + bias -> q_out (qd) and the new token's K/V rows written straight into the pool slot
+ * slot_of[*len_dev or len_host].  replaces: qwen2/language_forward.py:183,80-82 + generate/streaming_cache.py:72-73. */
+int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out, void* k_planes,
+                 void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd, int kd, int D, int n_slots,
+                 void* stream);
+/* RMSNorm(x; ln_w) -> h[n] = silu(Wg[n] x) * (Wu[n] x), W = [gate(I) | up(I)] rows.  replaces: :200-201 (Qwen2MLP). */
+int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, const void* W, int ldw, void* h, int I, int K, void* stream);
+/* final RMSNorm -> last-row logits (fp32 copy of the bf16 value) -> penalty / suppression -> per-workgroup argmax
+ * candidates in ws (>= svlm_dec_lm_head_ws_bytes(V)); svlm_argmax_finish picks the winner and feeds it back
+ * (same state protocol as svlm_penalty_argmax).  replaces: qwen2/language_forward.py:315, qwen2/model_forward.py:243,
+ * generate/streaming_generate_qwen.py:73-104. */
+long long svlm_dec_lm_head_ws_bytes(int V);
+int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen, float penalty,
+                     const int* suppress, int n_suppress, void* ws, int V, int K, void* stream);
+int svlm_argmax_finish(const void* ws, int V, void* seen, int* tok_buf, int* state, int advance_kv, void* stream);
 
 #ifdef __cplusplus
 }

@@ -88,9 +88,17 @@ def rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
+# Key-tile size of the online-softmax restatement; None = one tile (global max).  flash-attn rounds
+# P = exp(s - running_max) to bf16 tile by tile, so its result depends (at the 2^-9 level per term) on the
+# tile order; tests use a second tile size to MEASURE that inherent noise floor (tests/test_engine_gpu.py).
+ATTN_TILE: Optional[int] = None
+
+
 def flash_attention(q, k, v, causal_offset: Optional[int], scale: float):
     """q (Hq, T, D), k/v (Hq, L, D) already GQA-expanded.  causal_offset=None: full
     attention; else query i sees keys <= causal_offset + i.  flash-attn numerics."""
+    if ATTN_TILE is not None:
+        return _flash_attention_tiled(q, k, v, causal_offset, scale, ATTN_TILE)
     s = torch.matmul(q.float(), k.float().transpose(1, 2)) * scale          # fp32 scores
     if causal_offset is not None:
         T, L = q.shape[1], k.shape[1]
@@ -102,6 +110,31 @@ def flash_attention(q, k, v, causal_offset: Optional[int], scale: float):
     l = p.sum(dim=-1, keepdim=True)
     o = torch.matmul(p.to(q.dtype).float(), v.float()) / l                  # P rounded before P.V
     return o.to(q.dtype)
+
+
+def _flash_attention_tiled(q, k, v, causal_offset, scale, tile):
+    """Online-softmax form (FlashAttention-2 Algorithm 1): per key tile, m_new = max(m, rowmax(S)),
+    P = exp(S - m_new) rounded to the activation dtype for P.V, O and l rescaled by exp(m - m_new)."""
+    H, T, D = q.shape
+    L = k.shape[1]
+    qf = q.float()
+    m = torch.full((H, T, 1), -1e30)
+    l = torch.zeros((H, T, 1))
+    o = torch.zeros((H, T, D))
+    qi = (torch.arange(T).unsqueeze(1) + causal_offset) if causal_offset is not None else None
+    for j0 in range(0, L, tile):
+        j1 = min(L, j0 + tile)
+        s = torch.matmul(qf, k[:, j0:j1].float().transpose(1, 2)) * scale
+        if qi is not None:
+            kj = torch.arange(j0, j1).unsqueeze(0)
+            s = s.masked_fill((kj > qi).unsqueeze(0), -1e30)
+        m_new = torch.maximum(m, s.max(dim=-1, keepdim=True).values)
+        alpha = torch.exp(m - m_new)
+        p = torch.where(s > -1e29, torch.exp(s - m_new), torch.zeros_like(s))
+        l = l * alpha + p.sum(dim=-1, keepdim=True)
+        o = o * alpha + torch.matmul(p.to(q.dtype).float(), v[:, j0:j1].float())
+        m = m_new
+    return (o / l).to(q.dtype)
 
 
 def quick_gelu(x):

@@ -1,0 +1,279 @@
+// Fused decode-step (T = 1) kernels: the small per-layer ops around each weight-streaming GEMV are
+// folded into its prologue / epilogue, because at batch 1 every separate launch costs ~4-5 us of
+// dependent memory latency while the work it does is nanoseconds.
+//
+//   svlm_dec_qkv       RMSNorm(x) -> [q|k|v] = W x + b -> q to a buffer, k and v STRAIGHT into the
+//                      KV pool slot of the new token (un-rotated)
+//                      (qwen2/language_forward.py:183,80-82 + StreamingCache.update, streaming_cache.py:72-73)
+//   svlm_dec_gate_up   RMSNorm(x) -> h = silu(Wg x) * (Wu x)            (Qwen2MLP, language_forward.py:200-201)
+//   svlm_dec_lm_head   final RMSNorm -> last-row logits (fp32 copy of the bf16 value) -> repetition penalty /
+//                      EOS suppression -> per-workgroup argmax candidates   (language_forward.py:315,
+//                      model_forward.py:243, streaming_generate_qwen.py:73-99)
+//   svlm_argmax_finish winner over the candidates + device-side token feedback
+// The o_proj and down_proj GEMVs keep using svlm_gemv_bf16 with its residual epilogue.
+//
+// All are HBM-bound weight streams: 16-B loads straight to VGPRs, the normalised activation row is
+// staged once per workgroup in LDS (bf16, rounded exactly where the eager module rounds).
+#include "common.h"
+
+extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+
+// xs[0..K) = bf16( w * bf16(x * rsqrt(mean(x^2) + eps)) )  (NORM)  or a plain copy.  256 threads.
+template <bool NORM>
+__device__ __forceinline__ void stage_x(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps, int K, bf16_t* xs) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float r = 1.f;
+  if (NORM) {
+    float ss = 0.f;
+    for (int c = tid * 8; c < K; c += 2048) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(x + c), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    r = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+  }
+  for (int c = tid * 8; c < K; c += 2048) {
+    u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + c);
+    if (NORM) {
+      float f[8], g[8];
+      unpack8(v, f);
+      unpack8(*reinterpret_cast<const u32x4_t*>(ln_w + c), g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = g[i] * rbf(f[i] * r);
+      v = pack8(f);
+    }
+    *reinterpret_cast<u32x4_t*>(xs + c) = v;
+  }
+  __syncthreads();
+}
+
+// acc[r] = W[row[r]] . xs   for NR rows of one wave
+template <int NR>
+__device__ __forceinline__ void wave_dots(const bf16_t* const (&wr)[NR], const bf16_t* xs, int K, float (&acc)[NR]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+  const int nfull = K / 512;
+#pragma unroll 2
+  for (int it = 0; it < nfull; ++it) {
+    const int c = it * 512 + lane * 8;
+    u32x4_t wv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
+    float xf[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(xs + c), xf);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float wf[8];
+      unpack8(wv[r], wf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
+    }
+  }
+  const int c = nfull * 512 + lane * 8;
+  if (c < K) {
+    float xf[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(xs + c), xf);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      float wf[8];
+      unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c)), wf);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
+}
+
+// ---------------------------------------------------------------- QKV + KV append
+template <int ROWS>
+__global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
+                                                      const bf16_t* __restrict__ W, int ldw, const bf16_t* __restrict__ bias,
+                                                      bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_planes,
+                                                      bf16_t* __restrict__ v_planes, const int* __restrict__ slot_of,
+                                                      const int* __restrict__ len_dev, int len_host, int N, int K, int qd, int kd,
+                                                      int D, int n_slots) {
+  bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
+  stage_x<true>(x, ln_w, eps, K, xs);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + wave) * ROWS;
+  if (n0 >= N) return;
+  const bf16_t* wr[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, N - 1) * ldw;
+  float acc[ROWS];
+  wave_dots<ROWS>(wr, xs, K, acc);
+  if (lane == 0) {
+    const int slot = slot_of[len_dev ? *len_dev : len_host];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r;
+      if (n >= N) break;
+      const bf16_t v = f2bf(acc[r] + bf2f(bias[n]));
+      if (n < qd) {
+        q_out[n] = v;
+      } else {
+        const int j = n - qd;
+        const int jj = j < kd ? j : j - kd;
+        bf16_t* plane = j < kd ? k_planes : v_planes;
+        plane[((size_t)(jj / D) * n_slots + slot) * D + jj % D] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- gate/up + SwiGLU
+template <int ROWS>
+__global__ __launch_bounds__(256) void dec_gate_up_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
+                                                          const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ h, int I, int K) {
+  bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
+  stage_x<true>(x, ln_w, eps, K, xs);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + wave) * ROWS;
+  if (n0 >= I) return;
+  const bf16_t* wr[2 * ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int n = min(n0 + r, I - 1);
+    wr[r] = W + (size_t)n * ldw;               // gate row n
+    wr[ROWS + r] = W + (size_t)(I + n) * ldw;  // up row n
+  }
+  float acc[2 * ROWS];
+  wave_dots<2 * ROWS>(wr, xs, K, acc);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r;
+      if (n >= I) break;
+      const float g = rbf(acc[r]), u = rbf(acc[ROWS + r]);
+      h[n] = f2bf(apply_act(g, SVLM_ACT_SILU) * u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- lm_head + penalty + argmax candidates
+template <int ROWS>
+__global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
+                                                          const bf16_t* __restrict__ W, int ldw, float* __restrict__ logits,
+                                                          const unsigned char* __restrict__ seen, float penalty,
+                                                          const int* __restrict__ suppress, int n_suppress,
+                                                          float* __restrict__ part_val, int* __restrict__ part_idx, int V, int K) {
+  bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
+  stage_x<true>(x, ln_w, eps, K, xs);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n0 = (blockIdx.x * 4 + wave) * ROWS;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (n0 < V) {
+    const bf16_t* wr[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, V - 1) * ldw;
+    float acc[ROWS];
+    wave_dots<ROWS>(wr, xs, K, acc);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int n = n0 + r;
+      if (n >= V) break;
+      float v = rbf(acc[r]);
+      if (lane == 0) logits[n] = v;
+      if (seen && seen[n]) v = v < 0.f ? v * penalty : v / penalty;
+      for (int s = 0; s < n_suppress; ++s)
+        if (suppress[s] == n) v = -INFINITY;
+      if (v > best || (v == best && n < bi)) { best = v; bi = n; }
+    }
+  }
+  __shared__ float sb[4];
+  __shared__ int si[4];
+  if (lane == 0) { sb[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sb[w] > best || (sb[w] == best && si[w] < bi)) { best = sb[w]; bi = si[w]; }
+    part_val[blockIdx.x] = best;
+    part_idx[blockIdx.x] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_finish_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                            int n_parts, unsigned char* seen, int* tok_buf, int* state, int advance_kv) {
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n_parts; i += 256) {
+    const float v = part_val[i];
+    const int n = part_idx[i];
+    if (v > best || (v == best && n < bi)) { best = v; bi = n; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  __shared__ float sb[4];
+  __shared__ int si[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sb[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sb[w] > best || (sb[w] == best && si[w] < bi)) { best = sb[w]; bi = si[w]; }
+    if (bi == 0x7fffffff) bi = 0;
+    const int cur = state[1] + 1;
+    tok_buf[cur] = bi;
+    state[1] = cur;
+    state[0] += advance_kv;
+    if (seen) seen[bi] = 1;
+  }
+}
+
+// ================================================================ launchers
+static inline bool smem_ok(int K) { return K > 0 && K % 8 == 0 && K * 2 <= 64 * 1024; }
+
+extern "C" int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out,
+                            void* k_planes, void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd,
+                            int kd, int D, int n_slots, void* stream) {
+  SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0, "svlm_dec_qkv: bad K=%d ldw=%d", K, ldw);
+  SVLM_CHECK_ARG(qd > 0 && kd > 0 && D > 0 && kd % D == 0 && n_slots > 0 && bias != nullptr, "svlm_dec_qkv: bad qd=%d kd=%d D=%d", qd, kd, D);
+  const int N = qd + 2 * kd;
+  dec_qkv_kernel<1><<<(N + 3) / 4, 256, K * 2, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw,
+                                                                      (const bf16_t*)bias, (bf16_t*)q_out, (bf16_t*)k_planes,
+                                                                      (bf16_t*)v_planes, slot_of, len_dev, len_host, N, K, qd, kd, D, n_slots);
+  return svlm_check_launch("svlm_dec_qkv");
+}
+
+extern "C" int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, const void* W, int ldw, void* h, int I, int K, void* stream) {
+  SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0 && I > 0, "svlm_dec_gate_up: bad I=%d K=%d ldw=%d", I, K, ldw);
+  dec_gate_up_kernel<2><<<(I + 7) / 8, 256, K * 2, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw,
+                                                                         (bf16_t*)h, I, K);
+  return svlm_check_launch("svlm_dec_gate_up");
+}
+
+#define LM_ROWS 4
+extern "C" long long svlm_dec_lm_head_ws_bytes(int V) { return V <= 0 ? SVLM_EINVAL : (long long)((V + 4 * LM_ROWS - 1) / (4 * LM_ROWS)) * 8; }
+
+extern "C" int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen,
+                                float penalty, const int* suppress, int n_suppress, void* ws, int V, int K, void* stream) {
+  SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0 && V > 0, "svlm_dec_lm_head: bad V=%d K=%d ldw=%d", V, K, ldw);
+  SVLM_CHECK_ARG(penalty > 0.f && n_suppress >= 0 && n_suppress <= 8 && ws != nullptr && logits != nullptr, "svlm_dec_lm_head: bad sampling args");
+  const int nb = (V + 4 * LM_ROWS - 1) / (4 * LM_ROWS);
+  float* pv = (float*)ws;
+  int* pi = (int*)(pv + nb);
+  dec_lm_head_kernel<LM_ROWS><<<nb, 256, K * 2, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, logits,
+                                                                       (const unsigned char*)seen, penalty, suppress, n_suppress, pv, pi, V, K);
+  return svlm_check_launch("svlm_dec_lm_head");
+}
+
+extern "C" int svlm_argmax_finish(const void* ws, int V, void* seen, int* tok_buf, int* state, int advance_kv, void* stream) {
+  SVLM_CHECK_ARG(V > 0 && ws != nullptr, "svlm_argmax_finish: bad args");
+  const int nb = (V + 4 * LM_ROWS - 1) / (4 * LM_ROWS);
+  const float* pv = (const float*)ws;
+  const int* pi = (const int*)(pv + nb);
+  argmax_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(pv, pi, nb, (unsigned char*)seen, tok_buf, state, advance_kv);
+  return svlm_check_launch("svlm_argmax_finish");
+}

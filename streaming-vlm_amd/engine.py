@@ -56,7 +56,7 @@ class SvlmEngine:
         if decode_chunk is None:
             # split-KV chunk: enough workgroups (n_splits * Hkv) to cover the chip at the bounded window
             target = max(1, 256 // tc.num_kv_heads)
-            decode_chunk = max(16, min(256, 16 * int(math.ceil(self.max_len / target / 16))))
+            decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / target / 16))))
         self.decode_chunk = int(decode_chunk)
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
         dev = self.device
@@ -82,6 +82,7 @@ class SvlmEngine:
         self.d_gu = torch.zeros(2 * tc.intermediate_size, dtype=BF16, device=dev)
         self.d_h = torch.zeros(tc.intermediate_size, dtype=BF16, device=dev)
         self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, self.decode_chunk, dev)
+        self.d_sws = ops.sampling_ws(V, dev)
         self._vit_rope_cache = {}
         self._graph = None
         self._graph_key = None
@@ -177,37 +178,35 @@ class SvlmEngine:
         o.gemv(self.d_xn, w.lm_head, out_f32=self.logits)
 
     def _decode_step_launch(self, c: KVPool):
-        """One token: every kernel reads the KV length / token index from `self.state` on the device."""
+        """One token, 6 launches per layer: [norm+QKV+append] [attn split] [attn combine] [o+res] [norm+gate/up+SwiGLU]
+        [down+res]; every kernel reads the KV length / token index from `self.state` on the device."""
         o, w, tc = self.ops, self.w, self.cfg.text
         H, qd, kd = tc.hidden_size, self.qd, self.kd
         kv_len = self.state[0:1]
         scale = 1.0 / math.sqrt(tc.head_dim)
-        x1 = self.d_x.view(1, H)
-        o.gather_rows(w.embed, None, self.tok_buf, x1, idx_off=self.state[1:2])
-        k_new = self.d_qkv[qd:qd + kd].view(1, kd)
-        v_new = self.d_qkv[qd + kd:].view(1, kd)
+        o.gather_rows(w.embed, None, self.tok_buf, self.d_x.view(1, H), idx_off=self.state[1:2])
         for li, lw in enumerate(w.layers):
-            o.rmsnorm(self.d_x, lw["ln1"], tc.rms_eps, out=self.d_xn)
-            o.gemv(self.d_xn, lw["qkv_w"], bias=lw["qkv_b"], out=self.d_qkv)
-            o.kv_append(k_new, v_new, c.pool, li, c.slot_of_dev, 0, 1, len_dev=kv_len)
+            o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
+                      len_dev=kv_len)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
                           self.max_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
-            o.rmsnorm(self.d_x, lw["ln2"], tc.rms_eps, out=self.d_xn)
-            o.gemv(self.d_xn, lw["gu_w"], out=self.d_gu)
-            o.silu_mul(self.d_gu.view(1, -1), out=self.d_h.view(1, -1))
+            o.dec_gate_up(self.d_x, lw["ln2"], tc.rms_eps, lw["gu_w"], self.d_h)
             o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)
-        o.rmsnorm(self.d_x, w.final_norm, tc.rms_eps, out=self.d_xn)
-        o.gemv(self.d_xn, w.lm_head, out_f32=self.logits)
+        o.dec_lm_head(self.d_x, w.final_norm, tc.rms_eps, w.lm_head, self.logits, self.seen if self._penalty != 1.0 else None,
+                      self._penalty, self._suppress, self.d_sws)
 
-    def _sample_launch(self, advance_kv: int):
-        self.ops.penalty_argmax(self.logits, self.seen if self._penalty != 1.0 else None, self._penalty, self._suppress,
-                                self.tok_buf, self.state, advance_kv)
+    def _sample_launch(self, advance_kv: int, fused: bool = False):
+        seen = self.seen if self._penalty != 1.0 else None
+        if fused:      # candidates already left in d_sws by dec_lm_head
+            self.ops.argmax_finish(self.d_sws, self.cfg.text.vocab_size, seen, self.tok_buf, self.state, advance_kv)
+        else:
+            self.ops.penalty_argmax(self.logits, seen, self._penalty, self._suppress, self.tok_buf, self.state, advance_kv, self.d_sws)
 
     def _decode_step(self, c: KVPool):
         if not self.use_graph:
             self._decode_step_launch(c)
-            self._sample_launch(1)
+            self._sample_launch(1, fused=True)
             return
         key = (id(c), self._penalty, self._suppress is not None)
         if self._graph is None or self._graph_key != key:
@@ -215,7 +214,7 @@ class SvlmEngine:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._decode_step_launch(c)
-                self._sample_launch(1)
+                self._sample_launch(1, fused=True)
             self._graph, self._graph_key = g, key
         self._graph.replay()
 

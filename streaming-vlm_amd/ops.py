@@ -248,7 +248,11 @@ class HipOps:
         assert ids.numel() >= n
         check(self.lib.svlm_mark_seen(_ptr(ids), n, _ptr(seen), seen.numel(), _stream()), "svlm_mark_seen")
 
-    def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv):
+    def sampling_ws(self, V, device):
+        n = max(self.lib.svlm_argmax_ws_bytes(), self.lib.svlm_dec_lm_head_ws_bytes(V))
+        return torch.empty((n // 4,), dtype=torch.float32, device=device)
+
+    def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv, ws):
         _req(logits, torch.float32, "argmax.logits", 1); _req(tok_buf, torch.int32, "argmax.tok_buf", 1)
         _req(state, torch.int32, "argmax.state", 1)
         if seen is not None:
@@ -258,5 +262,46 @@ class HipOps:
             _req(suppress, torch.int32, "argmax.suppress", 1)
             n_sup = suppress.numel()
         assert state.numel() >= 2
+        _req(ws, torch.float32, "argmax.ws", 1)
+        assert ws.numel() * 4 >= self.lib.svlm_argmax_ws_bytes()
         check(self.lib.svlm_penalty_argmax(_ptr(logits), logits.numel(), _ptr(seen), float(penalty), _ptr(suppress), n_sup,
-                                           _ptr(tok_buf), _ptr(state), int(advance_kv), _stream()), "svlm_penalty_argmax")
+                                           _ptr(tok_buf), _ptr(state), int(advance_kv), _ptr(ws), _stream()), "svlm_penalty_argmax")
+
+    # ------------------------------------------------------------------ fused decode step
+    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
+        _req(x, BF16, "dec_qkv.x", 1); _req(ln_w, BF16, "dec_qkv.ln_w", 1); _req(W, BF16, "dec_qkv.W", 2)
+        _req(bias, BF16, "dec_qkv.bias", 1); _req(q_out, BF16, "dec_qkv.q_out", 1); _req(slot_of, torch.int32, "dec_qkv.slot_of", 1)
+        _, _, Hkv, n_slots, D = pool.shape
+        N, K = W.shape
+        assert N == qd + 2 * kd == bias.numel() and kd == Hkv * D and x.numel() == K == ln_w.numel() and q_out.numel() >= qd
+        if len_dev is None:
+            assert 0 <= length < slot_of.numel()
+        kp, vp = self._planes(pool, layer)
+        check(self.lib.svlm_dec_qkv(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(q_out), _ptr(kp), _ptr(vp),
+                                    _ptr(slot_of), _ptr(len_dev), int(length), K, qd, kd, D, n_slots, _stream()), "svlm_dec_qkv")
+
+    def dec_gate_up(self, x, ln_w, eps, W, h):
+        _req(x, BF16, "dec_gate_up.x", 1); _req(ln_w, BF16, "dec_gate_up.ln_w", 1); _req(W, BF16, "dec_gate_up.W", 2); _req(h, BF16, "dec_gate_up.h", 1)
+        N, K = W.shape
+        assert N % 2 == 0 and h.numel() == N // 2 and x.numel() == K == ln_w.numel()
+        check(self.lib.svlm_dec_gate_up(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(h), N // 2, K, _stream()), "svlm_dec_gate_up")
+
+    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws):
+        _req(x, BF16, "dec_lm_head.x", 1); _req(ln_w, BF16, "dec_lm_head.ln_w", 1); _req(W, BF16, "dec_lm_head.W", 2)
+        _req(logits, torch.float32, "dec_lm_head.logits", 1); _req(ws, torch.float32, "dec_lm_head.ws", 1)
+        V, K = W.shape
+        assert logits.numel() == V and x.numel() == K == ln_w.numel()
+        assert ws.numel() * 4 >= self.lib.svlm_dec_lm_head_ws_bytes(V)
+        n_sup = 0
+        if seen is not None:
+            _req(seen, torch.uint8, "dec_lm_head.seen", 1); assert seen.numel() == V
+        if suppress is not None:
+            _req(suppress, torch.int32, "dec_lm_head.suppress", 1)
+            n_sup = suppress.numel()
+        check(self.lib.svlm_dec_lm_head(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(logits), _ptr(seen), float(penalty),
+                                        _ptr(suppress), n_sup, _ptr(ws), V, K, _stream()), "svlm_dec_lm_head")
+
+    def argmax_finish(self, ws, V, seen, tok_buf, state, advance_kv):
+        _req(ws, torch.float32, "argmax_finish.ws", 1); _req(tok_buf, torch.int32, "argmax_finish.tok_buf", 1)
+        _req(state, torch.int32, "argmax_finish.state", 1)
+        check(self.lib.svlm_argmax_finish(_ptr(ws), V, _ptr(seen), _ptr(tok_buf), _ptr(state), int(advance_kv), _stream()), "svlm_argmax_finish")

@@ -169,7 +169,28 @@ class RefOps:
     def mark_seen(self, ids, n, seen):
         seen[ids[:n].long()] = 1
 
-    def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv):
+    def sampling_ws(self, V, device):
+        return torch.zeros(4, dtype=torch.float32)
+
+    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
+        y = F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W, bias)[0]
+        q_out[:qd] = y[:qd]
+        self.kv_append(y[qd:qd + kd].reshape(1, -1), y[qd + kd:].reshape(1, -1), pool, layer, slot_of, length, 1, len_dev=len_dev)
+
+    def dec_gate_up(self, x, ln_w, eps, W, h):
+        y = F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W)
+        I = W.shape[0] // 2
+        h.copy_((F.silu(y[:, :I]) * y[:, I:])[0])
+
+    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws):
+        logits.copy_(F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W)[0].float())
+        self._pending = (logits, seen, penalty, suppress)
+
+    def argmax_finish(self, ws, V, seen, tok_buf, state, advance_kv):
+        logits, seen_, penalty, suppress = self._pending
+        self.penalty_argmax(logits, seen_, penalty, suppress, tok_buf, state, advance_kv, ws)
+
+    def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv, ws=None):
         sc = logits.clone()
         if seen is not None:
             m = seen.bool()

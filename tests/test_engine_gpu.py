@@ -3,10 +3,11 @@ stream and the same seeded weights.
 
 Bars
   * eviction traces (every prune/move with its closed interval) and KV lengths: identical;
-  * last-row logits of every forward: relative error max|d|/max|ref| <= 2e-2 and mean|d|/max|ref| <= 2e-3.
-    Both sides round to bf16 at the same ~12 points per layer; the HIP kernels accumulate in a different
-    order, so single bf16 flips (2^-8 relative) propagate through the layers -- this is the noise floor
-    of bf16, not an implementation difference (DESIGN.md "Numerics");
+  * last-row logits of every forward: both sides round to bf16 at the same ~12 points per layer, and
+    flash attention rounds P = exp(s - running max) to bf16 tile by tile, so ANY two valid tilings differ by
+    single bf16 flips that propagate through the layers.  The test measures that floor on the oracle itself
+    (global-max vs 32-key tiles) and requires the HIP path to stay within 2.5x of it
+    (mean|d|/max|ref| <= 2.5*floor + 5e-4, max <= 2.5*floor + 5e-3; DESIGN.md "Numerics");
   * greedy token ids: exact on streams whose oracle top-2 margin exceeds the measured logit noise;
     where a margin is inside the noise the argmax is not defined by the arithmetic and the test
     reports it instead of failing.
@@ -19,10 +20,36 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+def _noise_floor(cfg, sd, n_chunks, ref, **kw):
+    """Logit error between two equally valid flash-attention tilings of the ORACLE itself (global max vs
+    32-key online tiles): the rounding noise any implementation of the reference numerics carries."""
+    from oracle import model as om
+    om.ATTN_TILE = 32
+    try:
+        alt = H.run_oracle_stream(cfg, sd, n_chunks, keep_logits=True, **kw)
+    finally:
+        om.ATTN_TILE = None
+    fmax = fmean = 0.0
+    for i in range(n_chunks):
+        if alt["new_tokens"][i] != ref["new_tokens"][i]:
+            # histories diverge after this chunk; compare only what both computed from identical inputs
+            for a, b, ta, tb in zip(alt["logits"][i], ref["logits"][i], alt["new_tokens"][i], ref["new_tokens"][i]):
+                d = (a - b).abs(); sc = float(b.abs().max())
+                fmax, fmean = max(fmax, float(d.max()) / sc), max(fmean, float(d.mean()) / sc)
+                if ta != tb:
+                    break
+            break
+        for a, b in zip(alt["logits"][i], ref["logits"][i]):
+            d = (a - b).abs(); sc = float(b.abs().max())
+            fmax, fmean = max(fmax, float(d.max()) / sc), max(fmean, float(d.mean()) / sc)
+    return fmax, fmean
+
+
 def _compare(cfg, sd, n_chunks, model, **kw):
     import streaming_vlm_amd as S  # noqa: F401
     _, trace, counts, ids_log = H.run_engine_stream(model, n_chunks, keep_logits=True, **kw)
     ref = H.run_oracle_stream(cfg, sd, n_chunks, keep_logits=True, **kw)
+    floor_max, floor_mean = _noise_floor(cfg, sd, n_chunks, ref, **kw)
     assert trace == ref["trace"], f"eviction indices differ:\n{trace}\n{ref['trace']}"
     worst_max = worst_mean = 0.0
     diverged = False
@@ -43,8 +70,11 @@ def _compare(cfg, sd, n_chunks, model, **kw):
                 assert margin <= 4 * noise, "greedy token differs although the oracle margin is far above the noise"
                 diverged = True          # histories differ from here on; stop comparing
                 break
-    print(f"[e2e] logits: max rel err {worst_max:.3e}, mean rel err {worst_mean:.3e}; diverged={diverged}")
-    assert worst_max <= 2e-2 and worst_mean <= 2e-3
+    print(f"[e2e] logits: max rel err {worst_max:.3e}, mean rel err {worst_mean:.3e}; oracle-vs-oracle tiling noise floor "
+          f"max {floor_max:.3e} mean {floor_mean:.3e}; diverged={diverged}")
+    # the HIP path may not be further from the oracle than ~2x what the oracle is from itself under re-tiling
+    assert worst_mean <= 2.5 * floor_mean + 5e-4, (worst_mean, floor_mean)
+    assert worst_max <= 2.5 * floor_max + 5e-3, (worst_max, floor_max)
     return diverged
 
 

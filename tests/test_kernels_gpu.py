@@ -206,8 +206,8 @@ def _attn_setup(Hq, Hkv, L, cap, seed):
     return pool, slot_of, rope
 
 
-@pytest.mark.parametrize("Hq,Hkv,L,chunk", [(12, 2, 2352, 64), (28, 4, 4400, 128), (4, 2, 1, 16), (4, 2, 17, 16), (12, 2, 100, 32),
-                                            (8, 1, 333, 48), (12, 2, 2052, 16)])
+@pytest.mark.parametrize("Hq,Hkv,L,chunk", [(12, 2, 2352, 64), (12, 2, 2352, 32), (28, 4, 4400, 64), (4, 2, 1, 16), (4, 2, 17, 16),
+                                            (12, 2, 100, 32), (8, 1, 333, 48), (12, 2, 2052, 16), (3, 1, 70, 64), (10, 2, 130, 64)])
 def test_decode_attn(ops, ref, Hq, Hkv, L, chunk):
     cap = ((L + 63) // 64) * 64 + 64
     pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 10)
@@ -263,6 +263,7 @@ def test_penalty_argmax(ops, ref):
     ids = torch.randint(0, V, (500,), generator=g, dtype=torch.int32)
     top = int(torch.argmax(logits))
     ids[0] = top                                    # the raw winner is penalised
+    sws = ops.sampling_ws(V, "cuda")
     for suppress in (None, torch.tensor([151645, 151643], dtype=torch.int32)):
         seen_c = torch.zeros(V, dtype=torch.uint8)
         ref.mark_seen(ids, 500, seen_c)
@@ -276,10 +277,64 @@ def test_penalty_argmax(ops, ref):
             lg[151645] = 100.0
         for adv in (0, 1, 1):
             ref.penalty_argmax(lg, seen_c, 1.05, suppress, tb_c, st_c, adv)
-            ops.penalty_argmax(lg.cuda(), seen_g, 1.05, suppress.cuda() if suppress is not None else None, tb_g, st_g, adv)
+            ops.penalty_argmax(lg.cuda(), seen_g, 1.05, suppress.cuda() if suppress is not None else None, tb_g, st_g, adv, sws)
         assert torch.equal(tb_g.cpu(), tb_c) and torch.equal(st_g.cpu(), st_c) and torch.equal(seen_g.cpu(), seen_c)
     # ties resolve to the lowest index like torch.argmax
     flat = torch.zeros(V)
     tb, st = torch.zeros(4, dtype=torch.int32, device="cuda"), torch.tensor([0, -1], dtype=torch.int32, device="cuda")
-    ops.penalty_argmax(flat.cuda(), None, 1.0, None, tb, st, 0)
+    ops.penalty_argmax(flat.cuda(), None, 1.0, None, tb, st, 0, sws)
     assert int(tb[0]) == 0
+
+
+# ----------------------------------------------------------------------------- fused decode-step kernels
+@pytest.mark.parametrize("H,Hq,Hkv,I,V", [(1536, 12, 2, 8960, 151936), (3584, 28, 4, 18944, 152064), (256, 4, 2, 512, 151680)])
+def test_fused_decode_kernels(ops, ref, H, Hq, Hkv, I, V):
+    D = 128
+    qd, kd = Hq * D, Hkv * D
+    x, lnw = rnd((H,), 1, 2.0), rnd((H,), 2, 0.1) + 1
+    # --- norm + qkv + append
+    W, b = rnd((qd + 2 * kd, H), 3, 0.03), rnd((qd + 2 * kd,), 4, 0.1)
+    pool_c = rnd((2, 2, Hkv, 48, D), 5)
+    pool_g = pool_c.clone().cuda()
+    slot_of = torch.randperm(48, generator=torch.Generator().manual_seed(6)).to(torch.int32)
+    q_c, q_g = torch.zeros(qd + 2 * kd, dtype=BF16), torch.zeros(qd + 2 * kd, dtype=BF16, device="cuda")
+    ref.dec_qkv(x, lnw, 1e-6, W, b, q_c, pool_c, 1, slot_of, qd, kd, length=17)
+    len_dev = torch.tensor([17], dtype=torch.int32, device="cuda")
+    ops.dec_qkv(x.cuda(), lnw.cuda(), 1e-6, W.cuda(), b.cuda(), q_g, pool_g, 1, slot_of.cuda(), qd, kd, len_dev=len_dev)
+    close("dec_qkv q", q_g[:qd], q_c[:qd])
+    close("dec_qkv pool", pool_g, pool_c)
+    assert torch.equal(pool_g.cpu()[0], pool_c[0]), "other layers untouched"
+    # --- norm + gate/up + swiglu
+    Wgu = rnd((2 * I, H), 7, 0.03)
+    h_c, h_g = torch.zeros(I, dtype=BF16), torch.zeros(I, dtype=BF16, device="cuda")
+    ref.dec_gate_up(x, lnw, 1e-6, Wgu, h_c)
+    ops.dec_gate_up(x.cuda(), lnw.cuda(), 1e-6, Wgu.cuda(), h_g)
+    close("dec_gate_up", h_g, h_c)
+    # --- final norm + lm_head + penalty + argmax + feedback
+    Wl = rnd((V, H), 8, 0.03)
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, V, (300,), generator=g, dtype=torch.int32)
+    sup = torch.tensor([151645, 151643], dtype=torch.int32)
+    lg_c, lg_g = torch.zeros(V), torch.zeros(V, device="cuda")
+    seen_c = torch.zeros(V, dtype=torch.uint8)
+    ref.mark_seen(ids, 300, seen_c)
+    seen_g = seen_c.clone().cuda()
+    sws = ops.sampling_ws(V, "cuda")
+    tb_c, st_c = torch.zeros(4, dtype=torch.int32), torch.tensor([50, 0], dtype=torch.int32)
+    tb_g, st_g = tb_c.clone().cuda(), st_c.clone().cuda()
+    ref.dec_lm_head(x, lnw, 1e-6, Wl, lg_c, seen_c, 1.05, sup, None)
+    ref.argmax_finish(None, V, seen_c, tb_c, st_c, 1)
+    ops.dec_lm_head(x.cuda(), lnw.cuda(), 1e-6, Wl.cuda(), lg_g, seen_g, 1.05, sup.cuda(), sws)
+    ops.argmax_finish(sws, V, seen_g, tb_g, st_g, 1)
+    close("dec_lm_head logits", lg_g, lg_c)
+    # the fused argmax must agree with a host argmax over the GPU's own logits (exact), and with the oracle
+    sc = lg_g.cpu().clone()
+    m = seen_c.bool().clone(); m[int(tb_c[1])] = seen_c[int(tb_c[1])].bool()
+    seen0 = torch.zeros(V, dtype=torch.uint8); ref.mark_seen(ids, 300, seen0)
+    mm = seen0.bool()
+    sc[mm] = torch.where(sc[mm] < 0, sc[mm] * 1.05, sc[mm] / 1.05)
+    sc[sup.long()] = float("-inf")
+    assert int(tb_g[1]) == int(torch.argmax(sc)), "fused argmax != argmax of its own logits"
+    assert torch.equal(st_g.cpu(), st_c)
+    if int(tb_g[1]) != int(tb_c[1]):
+        print("[fused] token differs from oracle (top-2 margin inside rounding noise)")
