@@ -44,10 +44,11 @@ const char* svlm_last_error(void); /* [host] */
 int svlm_device_cus(void);
 
 /* C[M,N] = bf16(act(bf16(A[M,K].W[N,K]^T + bias)) + residual).  bias/residual may be NULL.
+ * ws (may be NULL): fp32 scratch for split-K partial slabs, used when the tile grid alone cannot fill the chip.
  * replaces: nn.Linear / Conv3d-as-GEMM at qwen2/vision_forward.py:14,33,57,43-49,80 and
  * qwen2/language_forward.py:80-82,161,201 (prefill rows). */
 int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
-                   void* C, int ldc, int M, int N, int K, int act, void* stream);
+                   void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream);
 
 /* y[N] = same epilogue for one row x[K] (decode step); y (bf16) and/or y_f32 (fp32 copy of the
  * bf16-rounded value: the `.float()` of streaming_generate_qwen.py:73) may be NULL.

@@ -8,9 +8,13 @@
 // Replaces (reference call sites, all third-party GEMMs): qwen2/vision_forward.py:14,33,57 and the
 // VisionMlp / PatchMerger linears (:43-49,80), qwen2/language_forward.py:80-82,161 and Qwen2MLP (:201).
 //
-// Tile: (32*TM) x 128 x 64, 256 threads = 4 waves as 2(m) x 2(n); per wave TM x 4 tiles of
-// v_mfma_f32_16x16x32_bf16.  LDS rows padded to 144 B (conflict-free ds_read_b128 over 16 rows),
-// global->register prefetch of tile k+1 overlaps the MFMAs of tile k.
+// Tile (32*TM) x 128 x 64, 256 threads = 4 waves as 2(m) x 2(n); per wave TM x 4 tiles of
+// v_mfma_f32_16x16x32_bf16.  Two LDS buffers (rows padded to 144 B: conflict-free ds_read_b128 over
+// 16 rows) and a two-deep register ring: the global loads of tile k+3 are issued while tile k is
+// computed, so every load has two full iterations to land and there is one barrier per K-tile.
+// The path's shapes are skinny (M = 275..1024, N = 1280..5120) with long K (up to 8960): when the
+// tile grid cannot cover the 256 CUs the K range is split over grid.z, fp32 partial slabs go to a
+// caller-provided workspace and a second kernel sums them and applies the epilogue.
 #include "common.h"
 
 #define GEMM_BN 128
@@ -22,44 +26,46 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         const bf16_t* __restrict__ bias,
                                                         const bf16_t* residual, int ldr,
-                                                        bf16_t* C, int ldc, int M, int N, int K, int act) {
+                                                        bf16_t* C, int ldc, float* __restrict__ partial,
+                                                        int M, int N, int K, int k_per_split, int act) {
   constexpr int BM = 32 * TM;
   constexpr int A_PASSES = BM / 32;
   constexpr int W_PASSES = GEMM_BN / 32;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[(BM + GEMM_BN) * GEMM_LD];
-  bf16_t* As = smem;
-  bf16_t* Ws = smem + BM * GEMM_LD;
+  constexpr int STAGE = (BM + GEMM_BN) * GEMM_LD;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GEMM_BN;
   const int lrow = tid >> 3, lchunk = tid & 7;  // loader: 8 threads cover one 128-B row segment
+  const int k_begin = blockIdx.z * k_per_split;
+  const int k_end = min(K, k_begin + k_per_split);
+  const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
 
-  u32x4_t ra[A_PASSES], rw[W_PASSES];
-  auto load_tile = [&](int k0) {
-    const int k = k0 + lchunk * 8;
-    const bool kin = k < K;
+  const bf16_t* a_ptr[A_PASSES];
+  const bf16_t* w_ptr[W_PASSES];
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) {
-      int r = m0 + p * 32 + lrow;
-      r = r < M ? r : M - 1;
-      ra[p] = kin ? *reinterpret_cast<const u32x4_t*>(A + (size_t)r * lda + k) : u32x4_t{0, 0, 0, 0};
-    }
+  for (int p = 0; p < A_PASSES; ++p) a_ptr[p] = A + (size_t)min(m0 + p * 32 + lrow, M - 1) * lda + lchunk * 8;
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) {
-      int r = n0 + p * 32 + lrow;
-      r = r < N ? r : N - 1;
-      rw[p] = kin ? *reinterpret_cast<const u32x4_t*>(W + (size_t)r * ldw + k) : u32x4_t{0, 0, 0, 0};
-    }
+  for (int p = 0; p < W_PASSES; ++p) w_ptr[p] = W + (size_t)min(n0 + p * 32 + lrow, N - 1) * ldw + lchunk * 8;
+
+  u32x4_t ra0[A_PASSES], rw0[W_PASSES], ra1[A_PASSES], rw1[W_PASSES];
+  auto load_tile = [&](int kt, u32x4_t (&ra)[A_PASSES], u32x4_t (&rw)[W_PASSES]) {
+    const int k0 = k_begin + kt * GEMM_BK;
+    const bool kin = kt < nk && (k0 + lchunk * 8) < k_end;
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) ra[p] = kin ? *reinterpret_cast<const u32x4_t*>(a_ptr[p] + k0) : u32x4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < W_PASSES; ++p) rw[p] = kin ? *reinterpret_cast<const u32x4_t*>(w_ptr[p] + k0) : u32x4_t{0, 0, 0, 0};
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf, const u32x4_t (&ra)[A_PASSES], const u32x4_t (&rw)[W_PASSES]) {
+    bf16_t* As = smem + buf * STAGE;
+    bf16_t* Ws = As + BM * GEMM_LD;
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p)
-      *reinterpret_cast<u32x4_t*>(As + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = ra[p];
+    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<u32x4_t*>(As + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = ra[p];
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p)
-      *reinterpret_cast<u32x4_t*>(Ws + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = rw[p];
+    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<u32x4_t*>(Ws + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = rw[p];
   };
 
   f32x4_t acc[TM][4];
@@ -68,13 +74,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (K + GEMM_BK - 1) / GEMM_BK;
-  load_tile(0);
-  store_tile();
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile((kt + 1) * GEMM_BK);
+  auto compute = [&](int buf) {
+    const bf16_t* As = smem + buf * STAGE;
+    const bf16_t* Ws = As + BM * GEMM_LD;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t af[TM], wf[4];
@@ -90,11 +93,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
+  };
+
+  // prologue: tile 0 -> LDS[0]; tiles 1, 2 in flight in the register ring
+  load_tile(0, ra0, rw0);
+  load_tile(1, ra1, rw1);
+  store_tile(0, ra0, rw0);
+  load_tile(2, ra0, rw0);
+  __syncthreads();
+  // steady state, unrolled by two so that the ring slots are named registers
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even step: LDS[0] holds tile kt; ring slot 1 holds tile kt+1, slot 0 holds tile kt+2
+    if (kt + 1 < nk) store_tile(1, ra1, rw1);
+    load_tile(kt + 3, ra1, rw1);
+    compute(0);
     __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
-      __syncthreads();
-    }
+    if (kt + 1 >= nk) break;
+    // odd step: LDS[1] holds tile kt+1; slot 0 holds tile kt+2, slot 1 holds tile kt+3
+    if (kt + 2 < nk) store_tile(0, ra0, rw0);
+    load_tile(kt + 4, ra0, rw0);
+    compute(1);
+    __syncthreads();
   }
 
   // epilogue: lane holds m = fr (column of D), n = 4*fq + r (rows of D)
@@ -106,6 +125,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + fq * 4;
       if (n >= N) continue;
+      if (partial) {  // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
+        *reinterpret_cast<f32x4_t*>(partial + ((size_t)blockIdx.z * M + m) * N + n) = acc[i][j];
+        continue;
+      }
       float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (bias) {
         u32x2_t bv = *reinterpret_cast<const u32x2_t*>(bias + n);
@@ -125,8 +148,40 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   }
 }
 
+// C = epi(sum_z partial[z]) -- one thread per 4 consecutive n
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
+                                                                 const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
+                                                                 bf16_t* C, int ldc, int M, int N, int act) {
+  const int n4 = N / 4;
+  const size_t total = (size_t)M * n4;
+  const size_t slab = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i % n4) * 4;
+    f32x4_t s = *reinterpret_cast<const f32x4_t*>(partial + (size_t)m * N + n);
+    for (int z = 1; z < splits; ++z) {
+      const f32x4_t p = *reinterpret_cast<const f32x4_t*>(partial + z * slab + (size_t)m * N + n);
+      s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
+    }
+    float y[4] = {s[0], s[1], s[2], s[3]};
+    if (bias) {
+      u32x2_t bv = *reinterpret_cast<const u32x2_t*>(bias + n);
+      y[0] += lo_bf(bv[0]); y[1] += hi_bf(bv[0]); y[2] += lo_bf(bv[1]); y[3] += hi_bf(bv[1]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = apply_act(rbf(y[r]), act);
+    if (residual) {
+      u32x2_t rv = *reinterpret_cast<const u32x2_t*>(residual + (size_t)m * ldr + n);
+      y[0] = y[0] + lo_bf(rv[0]); y[1] = y[1] + hi_bf(rv[0]); y[2] = y[2] + lo_bf(rv[1]); y[3] = y[3] + hi_bf(rv[1]);
+    }
+    u32x2_t o;
+    o[0] = pack2(y[0], y[1]);
+    o[1] = pack2(y[2], y[3]);
+    *reinterpret_cast<u32x2_t*>(C + (size_t)m * ldc + n) = o;
+  }
+}
+
 extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
-                              void* C, int ldc, int M, int N, int K, int act, void* stream) {
+                              void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream) {
   SVLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "svlm_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
   SVLM_CHECK_ARG(K % 8 == 0 && N % 4 == 0, "svlm_gemm_bf16: K=%d must be a multiple of 8 and N=%d of 4", K, N);
   SVLM_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0),
@@ -134,18 +189,43 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
   SVLM_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "svlm_gemm_bf16: leading dim smaller than row length");
   SVLM_CHECK_ARG(act >= 0 && act <= 3, "svlm_gemm_bf16: unknown activation %d", act);
   if (M == 0) return SVLM_OK;
+  hipStream_t st = (hipStream_t)stream;
   const int gn = (N + GEMM_BN - 1) / GEMM_BN;
-  // small-M shapes use 64-row tiles so that the grid still covers the chip
-  const bool small = (M <= 64) || ((long long)((M + 127) / 128) * gn < 256 && M % 128 != 0 && M % 128 <= 64) ||
-                     ((long long)((M + 127) / 128) * gn < 128);
-  if (small) {
-    dim3 grid(gn, (M + 63) / 64);
-    gemm_bf16_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                                                              (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N, K, act);
-  } else {
-    dim3 grid(gn, (M + 127) / 128);
-    gemm_bf16_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias,
-                                                              (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N, K, act);
+  // 64-row tiles whenever 128-row tiles would leave CUs idle (or waste most of a ragged last tile)
+  const long long tiles128 = (long long)((M + 127) / 128) * gn;
+  const int waste128 = (M + 127) / 128 * 128 - M, waste64 = (M + 63) / 64 * 64 - M;
+  const bool small = (M <= 64) || tiles128 < 256 || (waste128 - waste64 >= 64);
+  const int bm = small ? 64 : 128;
+  const int gm = (M + bm - 1) / bm;
+  const long long tiles = (long long)gm * gn;
+  // split K until ~2 workgroups per CU, keeping >= 512 of K per split
+  int splits = 1;
+  if (ws != nullptr && tiles < 384 && K >= 1024) {
+    splits = (int)((512 + tiles - 1) / tiles);
+    if (splits > K / 512) splits = K / 512;
+    if (splits > 16) splits = 16;
+    while (splits > 1 && (long long)splits * M * N * 4 > ws_bytes) --splits;
+    if (splits < 1) splits = 1;
   }
-  return svlm_check_launch("svlm_gemm_bf16");
+  int kps = K;
+  if (splits > 1) {
+    kps = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+    splits = (K + kps - 1) / kps;
+  }
+  float* partial = splits > 1 ? (float*)ws : nullptr;
+  dim3 grid(gn, gm, splits);
+  if (small) {
+    gemm_bf16_kernel<2><<<grid, 256, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                             (bf16_t*)C, ldc, partial, M, N, K, kps, act);
+  } else {
+    gemm_bf16_kernel<4><<<grid, 256, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                             (bf16_t*)C, ldc, partial, M, N, K, kps, act);
+  }
+  int rc = svlm_check_launch("svlm_gemm_bf16");
+  if (rc || splits == 1) return rc;
+  const size_t total = (size_t)M * (N / 4);
+  int rg = (int)((total + 255) / 256);
+  rg = rg > 2048 ? 2048 : rg;
+  gemm_splitk_reduce_kernel<<<rg, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N, act);
+  return svlm_check_launch("svlm_gemm_bf16(split-K reduce)");
 }

@@ -42,6 +42,15 @@ class HipOps:
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.SvlmError("no HIP device visible: the svlm hot path only runs on an MI355X (gfx950) GPU")
+        self._gemm_ws = {}          # per-device fp32 scratch for split-K slabs
+
+    GEMM_WS_BYTES = 96 << 20
+
+    def _ws(self, device):
+        key = str(device)
+        if key not in self._gemm_ws:
+            self._gemm_ws[key] = torch.empty(self.GEMM_WS_BYTES // 4, dtype=torch.float32, device=device)
+        return self._gemm_ws[key]
 
     # ------------------------------------------------------------------ dense
     def gemm(self, A, W, bias=None, residual=None, out=None, act=ACT_NONE):
@@ -63,8 +72,9 @@ class HipOps:
             _req(residual, BF16, "gemm.residual", 2)
             assert tuple(residual.shape) == (M, N)
             ldr = residual.stride(0)
+        ws = self._ws(A.device)
         check(self.lib.svlm_gemm_bf16(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual), ldr,
-                                      _ptr(out), out.stride(0), M, N, K, act, _stream()), "svlm_gemm_bf16")
+                                      _ptr(out), out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _stream()), "svlm_gemm_bf16")
         return out
 
     def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=ACT_NONE):
