@@ -21,6 +21,8 @@
 #define GEMM_BK 64
 #define GEMM_LD 72  // padded LDS row stride in bf16 (144 B)
 
+extern __shared__ __attribute__((aligned(16))) unsigned char gemm_dyn_smem[];
+
 template <int TM>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   constexpr int A_PASSES = BM / 32;
   constexpr int W_PASSES = GEMM_BN / 32;
   constexpr int STAGE = (BM + GEMM_BN) * GEMM_LD;
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE];
+  bf16_t* smem = reinterpret_cast<bf16_t*>(gemm_dyn_smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -214,11 +216,23 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
   }
   float* partial = splits > 1 ? (float*)ws : nullptr;
   dim3 grid(gn, gm, splits);
+  // LDS: two stages of (BM + 128) rows x 144 B -- above the 64 KB default for TM = 4, so opt in once
+  constexpr int LDS2 = 2 * (64 + GEMM_BN) * GEMM_LD * 2, LDS4 = 2 * (128 + GEMM_BN) * GEMM_LD * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS4);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", LDS4, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+      return SVLM_ELAUNCH;
+    }
+    attr_done = true;
+  }
   if (small) {
-    gemm_bf16_kernel<2><<<grid, 256, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+    gemm_bf16_kernel<2><<<grid, 256, LDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                              (bf16_t*)C, ldc, partial, M, N, K, kps, act);
   } else {
-    gemm_bf16_kernel<4><<<grid, 256, 0, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+    gemm_bf16_kernel<4><<<grid, 256, LDS4, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                              (bf16_t*)C, ldc, partial, M, N, K, kps, act);
   }
   int rc = svlm_check_launch("svlm_gemm_bf16");

@@ -59,6 +59,10 @@ def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
     (70, 512, 256, True, True, 3),          # tiny, silu
     (1, 36, 8, True, False, 0),             # degenerate
     (129, 132, 72, False, False, 0),        # ragged everything
+    (275, 1536, 1536, False, True, 0),      # 2B o_proj + residual (split-K)
+    (1024, 1280, 1280, True, True, 0),      # ViT proj (split-K 2)
+    (64, 256, 4096, True, False, 1),        # deep split-K with activation
+    (200, 128, 1000, False, False, 0),      # K not a multiple of 64, split-K tail
 ])
 def test_gemm(ops, ref, M, N, K, bias, res, act):
     A, W = rnd((M, K), 1), rnd((N, K), 2, 0.05)
