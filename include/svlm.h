@@ -102,10 +102,13 @@ int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v
                               const int* len_dev, int len_add, void* out, void* ws, int Hq, int Hkv, int D, int n_slots,
                               int max_len, int chunk, float scale, void* stream);
 /* Prefill attention: q (T, q_stride) un-rotated rows for logical positions L-T..L-1 (their K/V already
- * appended), causal bottom-right aligned; out (T, o_stride).  replaces: same lines at q_len = T. */
+ * appended), causal bottom-right aligned; out (T, o_stride); ws >= svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv)
+ * holds the rotated queries and this layer's rotated keys / gathered values in logical order.
+ * replaces: same lines at q_len = T. */
+long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv);
 int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_planes, const void* v_planes, const int* slot_of,
                                const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D, int n_slots,
-                               float scale, void* stream);
+                               float scale, void* ws, long long ws_bytes, void* stream);
 
 /* seen[id] = 1 for ids[0..n).  (input to the repetition penalty) */
 int svlm_mark_seen(const int* ids, int n, void* seen, int V, void* stream);

@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + fc);
   const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + fc);
   u32x4_t kraw[DA_MAX_STEPS], vraw[DA_MAX_STEPS], craw[DA_MAX_STEPS], sraw[DA_MAX_STEPS];
+  const int n_steps = (end - start + 15) >> 4;      // workgroup-uniform
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
+    if (it >= n_steps) break;
     kraw[it] = *reinterpret_cast<const u32x4_t*>(kp + (size_t)slots[it] * DA_D);
     vraw[it] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)slots[it] * DA_D);
     const bf16_t* csr = rope_cs + (size_t)rows[it] * DA_D;
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
+    if (it >= n_steps) break;
     const bool valid = start + it * 16 + wave * 4 + grp < end;
     u32x4_t kpr;
 #pragma unroll

@@ -1,61 +1,66 @@
 // Multi-query flash attention on MFMA (v_mfma_f32_16x16x32_bf16) for the two GEMM-shaped
 // attention sites of the path:
-//   * LLM prefill over the slot-mapped KV pool with RoPE-on-load, causal, GQA
+//   * LLM prefill, causal, GQA, RoPE-on-load from the slot-mapped KV pool
 //     (qwen2/language_forward.py:66-166; T ~ 275 queries x L ~ 2.3k keys per chunk)
 //   * ViT block-diagonal attention, one sequence per temporal grid, non-causal, d = 80
 //     (qwen2/vision_forward.py:6-34, flash_attn_varlen_func with cu_seqlens = [0, h*w, ...])
 // Numerics follow flash-attn: fp32 scores and online softmax, P rounded to bf16 before P.V,
 // fp32 accumulation, one final division and rounding.
 //
-// Both products put the LDS-staged operand in the MFMA "A" slot and keep the other in registers:
+// Prefill runs in two launches per layer: `rope_gather_kernel` applies the shrink-mode post-cache
+// M-RoPE (bf16 x*cos + rotate_half(x)*sin, qwen2/language_forward.py:9-64) ONCE to every cached key
+// while gathering K and V from their slots into logical order, and rotates the T query rows; the
+// attention kernel then streams dense tiles.  (The reference rotates all keys in every layer too,
+// and additionally materialises repeat_kv.)
+//
+// Attention kernel: a workgroup = 4 waves x 16 queries of one head.  Both products put the LDS-staged
+// operand in the MFMA "A" slot and keep the other in registers:
 //   S^T[key][q] = K[key][:] . Q[q][:]      (A = K rows from LDS,   B = Q fragment, loop-invariant)
 //   O^T[d][q]   = V^T[d][key] . P^T[key][q] (A = V^T rows from LDS, B = P, straight from the S^T
 //                                            accumulators: lane = query column in both products,
 //                                            so softmax stats, P and O never leave the lane)
 // The k-slot <-> key mapping of the second product is the permutation that makes the S^T
 // accumulator registers a valid B fragment; V^T is read with the same permutation.
+// Pipeline: two LDS stages; the global loads of key tile t+2 are issued before tile t is computed and
+// written to LDS one iteration later, one barrier per 32-key tile.
 #include "common.h"
 
 #define FA_KT 32        // keys per tile
 #define FA_VLD 40       // V^T LDS row stride (bf16): 80 B, conflict-free ds_read_b64 over 16 rows x 2 groups
+#define FA_THREADS 256
 
-template <int D, int DP, bool ROPE, bool WAVE_IS_HEAD>
-__global__ __launch_bounds__(512) void flash_attn_kernel(
+template <int D, int DP>
+__global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     const bf16_t* __restrict__ q, long q_row_stride, long q_head_stride, long q_seq_stride,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long kv_row_stride, long kv_head_stride, long kv_seq_stride,
-    const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs,
     bf16_t* __restrict__ out, long o_row_stride, long o_head_stride, long o_seq_stride,
     int T, int L, int causal_offset, int causal, int Hq, int Hkv, float scale) {
   constexpr int KLD = DP + 8;          // K LDS row stride (bf16): 272 B / 208 B, conflict-free ds_read_b128
   constexpr int CPR = D / 8;           // 16-B chunks per row
   constexpr int NKS = DP / 32;         // k-steps of the QK^T product
   constexpr int NDT = D / 16;          // d tiles of the PV product
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[FA_KT * KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[D * FA_VLD];
+  constexpr int NCH = (FA_KT * CPR + FA_THREADS - 1) / FA_THREADS;   // chunks staged per thread per tile
+  constexpr int KS_STAGE = FA_KT * KLD, VT_STAGE = D * FA_VLD;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[2 * KS_STAGE];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[2 * VT_STAGE];
 
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int G = Hq / Hkv;
-  const int seq = blockIdx.z;
-  int head, kvh, qbase;
-  if (WAVE_IS_HEAD) {
-    kvh = blockIdx.y;
-    head = kvh * G + wave;
-    qbase = blockIdx.x * 16;
-  } else {
-    head = blockIdx.y;
-    kvh = head / G;
-    qbase = (blockIdx.x * nw + wave) * 16;
-  }
+  const int seq = blockIdx.z, head = blockIdx.y;
+  const int kvh = head / (Hq / Hkv);
+  const int qbase = (blockIdx.x * 4 + wave) * 16;
   q += seq * q_seq_stride;
   k += seq * kv_seq_stride + kvh * kv_head_stride;
   v += seq * kv_seq_stride + kvh * kv_head_stride;
   out += seq * o_seq_stride;
 
-  // zero the K pad columns once (D < DP, ViT d=80 -> 96)
+  // zero the K pad columns of both stages once (D < DP, ViT d = 80 -> 96)
   if constexpr (DP > D) {
-    for (int i = tid; i < FA_KT * (DP - D); i += nthr) Ks[(i / (DP - D)) * KLD + D + i % (DP - D)] = 0;
+    for (int i = tid; i < 2 * FA_KT * (DP - D); i += FA_THREADS) {
+      const int st = i / (FA_KT * (DP - D)), r = i % (FA_KT * (DP - D));
+      Ks[st * KS_STAGE + (r / (DP - D)) * KLD + D + r % (DP - D)] = 0;
+    }
   }
 
   // ---- Q fragments (B operand): lane (fr, fq) holds Q[qbase+fr][ks*32 + fq*8 .. +7]
@@ -64,35 +69,11 @@ __global__ __launch_bounds__(512) void flash_attn_kernel(
   bf16x8_t qf[NKS];
   {
     const bf16_t* qr = q + (size_t)tq_c * q_row_stride + (size_t)head * q_head_stride;
-    u32x4_t raw[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int d0 = ks * 32 + fq * 8;
-      raw[ks] = d0 < D ? *reinterpret_cast<const u32x4_t*>(qr + d0) : u32x4_t{0, 0, 0, 0};
-    }
-    if constexpr (ROPE) {
-      // D == 128: partner of d is d ^ 64 -> k-step ks ^ 2, same lane
-      const bf16_t* csr = rope_cs + (size_t)(tq_c + causal_offset) * D;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int d0 = ks * 32 + fq * 8;
-        float x[8], xp[8], c[8], sn[8], o[8];
-        unpack8(raw[ks], x);
-        unpack8(raw[ks ^ 2], xp);
-        unpack8(*reinterpret_cast<const u32x4_t*>(csr + (d0 & 63)), c);
-        unpack8(*reinterpret_cast<const u32x4_t*>(csr + 64 + (d0 & 63)), sn);
-        const bool upper = d0 >= 64;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float rot = upper ? xp[i] : -xp[i];
-          o[i] = rbf(rbf(x[i] * c[i]) + rbf(rot * sn[i]));
-        }
-        u32x4_t pk = pack8(o);
-        qf[ks] = *reinterpret_cast<bf16x8_t*>(&pk);
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<bf16x8_t*>(&raw[ks]);
+      u32x4_t raw = d0 < D ? *reinterpret_cast<const u32x4_t*>(qr + d0) : u32x4_t{0, 0, 0, 0};
+      qf[ks] = *reinterpret_cast<bf16x8_t*>(&raw);
     }
   }
 
@@ -103,49 +84,52 @@ __global__ __launch_bounds__(512) void flash_attn_kernel(
 
   // keys needed by this workgroup
   int kmax = L;
-  if (causal) {
-    const int q_last = WAVE_IS_HEAD ? qbase + 15 : (blockIdx.x * nw + nw) * 16 - 1;
-    const int lim = min(q_last, T - 1) + causal_offset + 1;
-    kmax = min(L, lim);
-  }
+  if (causal) kmax = min(L, min(blockIdx.x * 64 + 63, T - 1) + causal_offset + 1);
   const int n_kt = (kmax + FA_KT - 1) / FA_KT;
 
-  for (int kt = 0; kt < n_kt; ++kt) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (rotated) and V^T
-    for (int idx = tid; idx < FA_KT * CPR; idx += nthr) {
+  // ---- staging: thread owns chunks idx = tid + i*256 of every tile
+  u32x4_t kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * FA_THREADS;
       const int row = idx / CPR, c = idx % CPR;
       const int j = kt * FA_KT + row;
-      u32x4_t kv4 = u32x4_t{0, 0, 0, 0}, vv4 = u32x4_t{0, 0, 0, 0};
-      if (j < L) {
-        const size_t roff = (size_t)(slot_of ? slot_of[j] : j) * kv_row_stride;
-        kv4 = *reinterpret_cast<const u32x4_t*>(k + roff + c * 8);
-        vv4 = *reinterpret_cast<const u32x4_t*>(v + roff + c * 8);
-        if constexpr (ROPE) {
-          const u32x4_t kp4 = *reinterpret_cast<const u32x4_t*>(k + roff + (c ^ 8) * 8);
-          const bf16_t* csr = rope_cs + (size_t)j * D;
-          float x[8], xp[8], cc[8], sn[8], o[8];
-          unpack8(kv4, x);
-          unpack8(kp4, xp);
-          unpack8(*reinterpret_cast<const u32x4_t*>(csr + (c & 7) * 8), cc);
-          unpack8(*reinterpret_cast<const u32x4_t*>(csr + 64 + (c & 7) * 8), sn);
-          const bool upper = c >= 8;
+      const bool ok = idx < FA_KT * CPR && kt < n_kt && j < L;
+      kreg[i] = ok ? *reinterpret_cast<const u32x4_t*>(k + (size_t)j * kv_row_stride + c * 8) : u32x4_t{0, 0, 0, 0};
+      vreg[i] = ok ? *reinterpret_cast<const u32x4_t*>(v + (size_t)j * kv_row_stride + c * 8) : u32x4_t{0, 0, 0, 0};
+    }
+  };
+  auto store_tile = [&](int st) {
+    bf16_t* ks_ = Ks + st * KS_STAGE;
+    bf16_t* vt_ = Vt + st * VT_STAGE;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float rot = upper ? xp[i] : -xp[i];
-            o[i] = rbf(rbf(x[i] * cc[i]) + rbf(rot * sn[i]));
-          }
-          kv4 = pack8(o);
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + i * FA_THREADS;
+      if (idx < FA_KT * CPR) {
+        const int row = idx / CPR, c = idx % CPR;
+        *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = kreg[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vt_[(c * 8 + 2 * e) * FA_VLD + row] = (bf16_t)(vreg[i][e] & 0xFFFFu);
+          vt_[(c * 8 + 2 * e + 1) * FA_VLD + row] = (bf16_t)(vreg[i][e] >> 16);
         }
       }
-      *reinterpret_cast<u32x4_t*>(Ks + row * KLD + c * 8) = kv4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        Vt[(c * 8 + 2 * i) * FA_VLD + row] = (bf16_t)(vv4[i] & 0xFFFFu);
-        Vt[(c * 8 + 2 * i + 1) * FA_VLD + row] = (bf16_t)(vv4[i] >> 16);
-      }
     }
-    __syncthreads();
+  };
+
+  load_tile(0);
+  __syncthreads();          // pad zeroing visible before the first K store lands next to it
+  store_tile(0);
+  load_tile(1);
+  __syncthreads();
+
+  for (int kt = 0; kt < n_kt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < n_kt) store_tile(st ^ 1);      // stage st^1 was last read in iteration kt-1 (barrier passed)
+    load_tile(kt + 2);
+    const bf16_t* ks_ = Ks + st * KS_STAGE;
+    const bf16_t* vt_ = Vt + st * VT_STAGE;
 
     // ---- S^T = K . Q^T   (two 16-key sub-tiles)
     f32x4_t sacc[2];
@@ -154,7 +138,7 @@ __global__ __launch_bounds__(512) void flash_attn_kernel(
       sacc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (sub * 16 + fr) * KLD + ks * 32 + fq * 8);
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ks_ + (sub * 16 + fr) * KLD + ks * 32 + fq * 8);
         sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], sacc[sub], 0, 0, 0);
       }
     }
@@ -190,7 +174,7 @@ __global__ __launch_bounds__(512) void flash_attn_kernel(
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      const bf16_t* vr = Vt + (dt * 16 + fr) * FA_VLD + fq * 4;
+      const bf16_t* vr = vt_ + (dt * 16 + fr) * FA_VLD + fq * 4;
       u32x4_t a4;
       const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vr);
       const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vr + 16);
@@ -200,10 +184,11 @@ __global__ __launch_bounds__(512) void flash_attn_kernel(
       for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
       oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
     }
+    __syncthreads();
   }
 
   // ---- epilogue: lane holds O[tq][dt*16 + 4*fq + r]
-  if (tq < T && (!WAVE_IS_HEAD || wave < G)) {
+  if (tq < T) {
     const float inv = 1.0f / l_run;
     bf16_t* orow = out + (size_t)tq * o_row_stride + (size_t)head * o_head_stride;
 #pragma unroll
@@ -216,20 +201,87 @@ __global__ __launch_bounds__(512) void flash_attn_kernel(
   }
 }
 
-// LLM prefill: q (T, Hq*128) rows, pool planes of one layer, out (T, Hq*128).
+// K: gather + rotate; V: gather; Q: rotate.  D = 128; one thread per 16-B chunk.
+//   k_rot, v_lin: (Hkv, L, 128) in logical order;  q_rot: (T, Hq*128)
+__global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restrict__ q, int q_stride,
+                                                          const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
+                                                          const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs,
+                                                          bf16_t* __restrict__ q_rot, bf16_t* __restrict__ k_rot,
+                                                          bf16_t* __restrict__ v_lin, int T, int L, int Hq, int Hkv, int n_slots) {
+  constexpr int D = 128, CPR = 16;
+  const long nk = (long)Hkv * L * CPR, nq = (long)T * Hq * CPR;
+  const long total = 2 * nk + nq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    if (i >= nk && i < 2 * nk) {                      // V: plain gather
+      const long t = i - nk;
+      const int c = (int)(t % CPR), j = (int)((t / CPR) % L), h = (int)(t / ((long)CPR * L));
+      *reinterpret_cast<u32x4_t*>(v_lin + ((size_t)h * L + j) * D + c * 8) =
+          *reinterpret_cast<const u32x4_t*>(v_planes + ((size_t)h * n_slots + slot_of[j]) * D + c * 8);
+      continue;
+    }
+    const bf16_t* src;
+    bf16_t* dst;
+    int c, pos;
+    if (i < nk) {
+      c = (int)(i % CPR);
+      const int j = (int)((i / CPR) % L), h = (int)(i / ((long)CPR * L));
+      src = k_planes + ((size_t)h * n_slots + slot_of[j]) * D;
+      dst = k_rot + ((size_t)h * L + j) * D;
+      pos = j;
+    } else {
+      const long t = i - 2 * nk;
+      c = (int)(t % CPR);
+      const int h = (int)((t / CPR) % Hq), r = (int)(t / ((long)CPR * Hq));
+      src = q + (size_t)r * q_stride + h * D;
+      dst = q_rot + ((size_t)r * Hq + h) * D;
+      pos = L - T + r;                                // right-aligned query positions (language_forward.py:44-53)
+    }
+    const bf16_t* csr = rope_cs + (size_t)pos * D;
+    float x[8], xp[8], cc[8], sn[8], o[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(src + c * 8), x);
+    unpack8(*reinterpret_cast<const u32x4_t*>(src + (c ^ 8) * 8), xp);
+    unpack8(*reinterpret_cast<const u32x4_t*>(csr + (c & 7) * 8), cc);
+    unpack8(*reinterpret_cast<const u32x4_t*>(csr + 64 + (c & 7) * 8), sn);
+    const bool upper = c >= 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float rot = upper ? xp[e] : -xp[e];
+      o[e] = rbf(rbf(x[e] * cc[e]) + rbf(rot * sn[e]));
+    }
+    *reinterpret_cast<u32x4_t*>(dst + c * 8) = pack8(o);
+  }
+}
+
+// workspace: q_rot (T*Hq*128) | k_rot (Hkv*L*128) | v_lin (Hkv*L*128)  bf16
+extern "C" long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv) {
+  if (T < 0 || L < 0 || Hq <= 0 || Hkv <= 0) return SVLM_EINVAL;
+  return ((long long)T * Hq + 2LL * Hkv * L) * 128 * 2;
+}
+
+// LLM prefill: q (T, Hq*128) un-rotated rows, pool planes of one layer, out (T, Hq*128).
 extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_planes, const void* v_planes, const int* slot_of,
                                           const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D,
-                                          int n_slots, float scale, void* stream) {
+                                          int n_slots, float scale, void* ws, long long ws_bytes, void* stream) {
   SVLM_CHECK_ARG(D == 128, "svlm_prefill_attn_ropeload: head_dim %d unsupported (128 only)", D);
-  SVLM_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= 8, "svlm_prefill_attn_ropeload: Hq=%d Hkv=%d (group must be <= 8)", Hq, Hkv);
+  SVLM_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "svlm_prefill_attn_ropeload: Hq=%d Hkv=%d", Hq, Hkv);
   SVLM_CHECK_ARG(T >= 0 && L >= T && n_slots > 0, "svlm_prefill_attn_ropeload: need 0 <= T=%d <= L=%d", T, L);
   SVLM_CHECK_ARG(q_stride % 8 == 0 && o_stride % 4 == 0, "svlm_prefill_attn_ropeload: strides must keep 16-B alignment");
+  SVLM_CHECK_ARG(ws != nullptr && ws_bytes >= svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv), "svlm_prefill_attn_ropeload: workspace too small (%lld B)", ws_bytes);
   if (T == 0) return SVLM_OK;
-  const int G = Hq / Hkv;
-  dim3 grid((T + 15) / 16, Hkv, 1);
-  flash_attn_kernel<128, 128, true, true><<<grid, 64 * G, 0, (hipStream_t)stream>>>(
-      (const bf16_t*)q, q_stride, D, 0, (const bf16_t*)k_planes, (const bf16_t*)v_planes, D, (long)n_slots * D, 0, slot_of,
-      (const bf16_t*)rope_cs, (bf16_t*)out, o_stride, D, 0, T, L, L - T, 1, Hq, Hkv, scale);
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* q_rot = (bf16_t*)ws;
+  bf16_t* k_rot = q_rot + (size_t)T * Hq * 128;
+  bf16_t* v_lin = k_rot + (size_t)Hkv * L * 128;
+  const long total = (2L * Hkv * L + (long)T * Hq) * 16;
+  int g = (int)((total + 255) / 256);
+  g = g > 4096 ? 4096 : g;
+  rope_gather_kernel<<<g, 256, 0, st>>>((const bf16_t*)q, q_stride, (const bf16_t*)k_planes, (const bf16_t*)v_planes, slot_of,
+                                       (const bf16_t*)rope_cs, q_rot, k_rot, v_lin, T, L, Hq, Hkv, n_slots);
+  int rc = svlm_check_launch("svlm_prefill_attn_ropeload(rope_gather)");
+  if (rc) return rc;
+  dim3 grid((T + 63) / 64, Hq, 1);
+  flash_attn_kernel<128, 128><<<grid, FA_THREADS, 0, st>>>(q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out,
+                                                           o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv, scale);
   return svlm_check_launch("svlm_prefill_attn_ropeload");
 }
 
@@ -242,12 +294,12 @@ extern "C" int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len,
   const long row = 3L * H * d;
   dim3 grid((seq_len + 63) / 64, H, n_seq);
   if (d == 80) {
-    flash_attn_kernel<80, 96, false, false><<<grid, 256, 0, (hipStream_t)stream>>>(
-        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, nullptr, nullptr, (bf16_t*)out,
+    flash_attn_kernel<80, 96><<<grid, FA_THREADS, 0, (hipStream_t)stream>>>(
+        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,
         (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale);
   } else {
-    flash_attn_kernel<128, 128, false, false><<<grid, 256, 0, (hipStream_t)stream>>>(
-        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, nullptr, nullptr, (bf16_t*)out,
+    flash_attn_kernel<128, 128><<<grid, FA_THREADS, 0, (hipStream_t)stream>>>(
+        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,
         (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale);
   }
   return svlm_check_launch("svlm_vit_attn");

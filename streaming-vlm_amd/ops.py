@@ -247,9 +247,15 @@ class HipOps:
         assert q.shape[0] >= T and q.shape[1] == Hq * D and out.shape[0] >= T and out.shape[1] == Hq * D
         assert T <= L <= slot_of.numel() and L <= rope_cs.shape[0] and rope_cs.shape[1] == D
         kp, vp = self._planes(pool, layer)
+        need = self.lib.svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv)
+        key = "pf" + str(q.device)
+        ws = self._gemm_ws.get(key)
+        if ws is None or ws.numel() * 2 < need:
+            ws = torch.empty(max(need // 2, 1 << 20), dtype=BF16, device=q.device)
+            self._gemm_ws[key] = ws
         check(self.lib.svlm_prefill_attn_ropeload(_ptr(q), q.stride(0), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(rope_cs), _ptr(out),
-                                                  out.stride(0), T, L, Hq, Hkv, D, n_slots, float(scale), _stream()),
-              "svlm_prefill_attn_ropeload")
+                                                  out.stride(0), T, L, Hq, Hkv, D, n_slots, float(scale), _ptr(ws), ws.numel() * 2,
+                                                  _stream()), "svlm_prefill_attn_ropeload")
         return out
 
     # ------------------------------------------------------------------ sampling

@@ -92,6 +92,7 @@ def test_gemm_rejects_bad_shapes(ops):
 @pytest.mark.parametrize("N,K,bias,res,f32", [
     (2048, 1536, True, False, False), (1536, 1536, False, True, False), (17920, 1536, False, False, False),
     (1536, 8960, False, True, False), (151936, 1536, False, False, True), (520, 264, True, True, False), (7, 8, False, False, True),
+    (3584, 18944, False, True, False), (100, 4104, True, False, False),
 ])
 def test_gemv(ops, ref, N, K, bias, res, f32):
     x, W = rnd((K,), 1), rnd((N, K), 2, 0.05)
