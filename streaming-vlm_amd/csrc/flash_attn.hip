@@ -16,7 +16,7 @@
 // Attention kernel: a workgroup = 4 waves x 16 queries of one head.  Both products put the LDS-staged
 // operand in the MFMA "A" slot and keep the other in registers:
 //   S^T[key][q] = K[key][:] . Q[q][:]      (A = K rows from LDS,   B = Q fragment, loop-invariant)
-//   O^T[d][q]   = V^T[d][key] . P^T[key][q] (A = V^T rows from LDS, B = P, straight from the S^T
+//   O^T[d][q]   = V^T[d][key] . P^T[key][q] (A = V^T via ds_read_b64_tr_b16 of row-major V in LDS, B = P, straight from the S^T
 //                                            accumulators: lane = query column in both products,
 //                                            so softmax stats, P and O never leave the lane)
 // The k-slot <-> key mapping of the second product is the permutation that makes the S^T
@@ -26,7 +26,8 @@
 #include "common.h"
 
 #define FA_KT 32        // keys per tile
-#define FA_VLD 40       // V^T LDS row stride (bf16): 80 B, conflict-free ds_read_b64 over 16 rows x 2 groups
+#define FA_VLD 144      // V LDS row stride (bf16): 288 B = 8 banks (mod 64) per key -> conflict-free ds_read_b64_tr_b16
+typedef short v4s_t __attribute__((ext_vector_type(4)));
 #define FA_THREADS 256
 
 template <int D, int DP>
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   constexpr int NKS = DP / 32;         // k-steps of the QK^T product
   constexpr int NDT = D / 16;          // d tiles of the PV product
   constexpr int NCH = (FA_KT * CPR + FA_THREADS - 1) / FA_THREADS;   // chunks staged per thread per tile
-  constexpr int KS_STAGE = FA_KT * KLD, VT_STAGE = D * FA_VLD;
+  constexpr int KS_STAGE = FA_KT * KLD, VT_STAGE = FA_KT * FA_VLD;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[2 * KS_STAGE];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[2 * VT_STAGE];
 
@@ -109,11 +110,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       if (idx < FA_KT * CPR) {
         const int row = idx / CPR, c = idx % CPR;
         *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = kreg[i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          vt_[(c * 8 + 2 * e) * FA_VLD + row] = (bf16_t)(vreg[i][e] & 0xFFFFu);
-          vt_[(c * 8 + 2 * e + 1) * FA_VLD + row] = (bf16_t)(vreg[i][e] >> 16);
-        }
+        *reinterpret_cast<u32x4_t*>(vt_ + row * FA_VLD + c * 8) = vreg[i];      // V stays row-major: transposed on read
       }
     }
   };
@@ -174,12 +171,12 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
-      const bf16_t* vr = vt_ + (dt * 16 + fr) * FA_VLD + fq * 4;
-      u32x4_t a4;
-      const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(vr);
-      const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(vr + 16);
-      a4[0] = lo[0]; a4[1] = lo[1]; a4[2] = hi[0]; a4[3] = hi[1];
-      const bf16x8_t a = *reinterpret_cast<bf16x8_t*>(&a4);
+      // ds_read_b64_tr_b16: lane fr of the 16-lane group supplies row (key) 4*fq + fr/4, columns 4*(fr%4)..+3 and
+      // receives column (d) dt*16 + fr of the 4 rows -> the V^T fragment without a transposed LDS image
+      const bf16_t* vr = vt_ + (fq * 4 + (fr >> 2)) * FA_VLD + dt * 16 + (fr & 3) * 4;
+      const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr));
+      const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr + 16 * FA_VLD));
+      const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
       oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
