@@ -137,19 +137,14 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import multi_stream as MS
+    dist, rank, world, local_rank = MS.init_distributed("nccl")          # nccl == RCCL over xGMI on ROCm
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     dev = torch.device("cuda", local_rank)
 
-    import streaming_vlm_amd as S
     from streaming_vlm_amd import config as C
     from streaming_vlm_amd.synthetic import ResidentProcessor, ResidentVideo
     from streaming_vlm_amd.weights import random_state_dict
@@ -171,10 +166,7 @@ def main():
     counts = []
 
     def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        MS.fence(dist, dev)
 
     def on_chunk(i):
         if i == 0:
@@ -192,17 +184,8 @@ def main():
     log(f"timed region done: {elapsed:.3f} s for {args.steps} chunks")
     frames = args.steps * frames_per_chunk
     tokens = sum(counts[args.warmup:])
-    stats = torch.tensor([frames, tokens, elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        allst = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(allst, stats)
-        allst = torch.stack(allst).cpu()
-    else:
-        allst = stats.cpu().unsqueeze(0)
-    t_max = float(allst[:, 2].max())
-    fps_total = float(allst[:, 0].sum()) / t_max
-    tps_total = float(allst[:, 1].sum()) / t_max
-    per_gpu_fps = (allst[:, 0] / allst[:, 2]).tolist()
+    agg = MS.aggregate(frames, tokens, elapsed, dist, dev)
+    t_max, fps_total, tps_total, per_gpu_fps = agg["t_max"], agg["frames_per_sec"], agg["tokens_per_sec"], agg["per_rank_frames_per_sec"]
 
     out = {
         "metric": "frames_per_sec", "value": round(fps_total, 3), "unit": "frames/s",

@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""Mint the golden vectors under tests/golden/ (run in the BUILD container, where /root/reference and the
+stock `transformers` are importable; the GPU box has neither the reference nor a need for this script).
+
+Sources, in order of authority:
+  ref_*      outputs of the reference's OWN importable modules (PYTHONPATH=/root/reference/src):
+             utils.get_qwen_range.get_qwen_range, inference.qwen2.pos_emb.get_rope_index, utils.vtt_utils.sec2ts.
+             The reference ships no tests or fixtures, so these are the only vectors it can pin itself.
+  hf_*       outputs of the installed transformers' Qwen2-VL modules (the third-party code the reference calls)
+             on a tiny seeded config: vision tower, decoder with DynamicCache, rotary tables, M-RoPE apply.
+  oracle_*   the oracle's own eviction traces / greedy tokens (regression anchors for the host logic).
+
+Only DATA is written (ids, shapes, numbers): no reference source text.
+    python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF_SRC = "/root/reference/src"
+
+IM_START, IM_END, USER, ASSISTANT = 151644, 151645, 872, 77091
+VSTART, VEND, VPAD, LF, TIME = 151652, 151653, 151656, 198, 1462
+PT = [19702, 1467]
+
+
+def build_sequences():
+    """Hand-built chat-template id sequences covering the edge cases of inference.py:114-119,402-405."""
+    def user(n_vid, with_time=True, query=(), lf=True):
+        s = [IM_START, USER, LF] + ([TIME, 28, 15, 13, 15, 12, 16, 13, 15, 82] if with_time else []) + [VSTART] + [VPAD] * n_vid + [VEND]
+        return s + list(query) + [IM_END] + ([LF] if lf else [])
+
+    def asst(toks, lf=True, end=True):
+        return [IM_START, ASSISTANT, LF] + list(toks) + ([IM_END] if end else []) + ([LF] if lf and end else [])
+
+    sys_ = [IM_START, 8948, LF, 2610, 525, 264, 10950, 17847, 13, IM_END, LF]
+    prev = lambda toks: [IM_START] + PT + [LF] + list(toks) + [IM_END, LF]
+    seqs = {}
+    seqs["two_rounds"] = sys_ + prev([100, 101, 102]) + user(4, query=[500, 501]) + asst([7, 8, 2503]) + user(4) + asst([9, 2503])
+    seqs["no_trailing_lf"] = sys_ + prev([]) + user(2) + asst([7, 2503], lf=False)
+    seqs["open_assistant"] = sys_ + prev([5]) + user(2) + asst([7], end=False)          # unterminated last segment
+    seqs["many_rounds"] = sys_ + prev(list(range(300, 340)))
+    for r in range(6):
+        seqs["many_rounds"] = seqs["many_rounds"] + user(6, query=[900] if r == 0 else ()) + asst([40 + r, 41 + r, 2503])
+    seqs["text_only"] = sys_ + prev([1, 2, 3])
+    seqs["vision_first"] = [VSTART] + [VPAD] * 4 + [VEND, 11, 12]
+    return seqs
+
+
+def gen_reference_vectors():
+    sys.path.insert(0, REF_SRC)
+    from streaming_vlm.utils.get_qwen_range import get_qwen_range as ref_range
+    from streaming_vlm.inference.qwen2.pos_emb import get_rope_index as ref_rope
+    from streaming_vlm.utils.vtt_utils import sec2ts as ref_sec2ts
+
+    seqs = build_sequences()
+    ranges = {}
+    for name, ids in seqs.items():
+        t = torch.tensor([ids])
+        cases = []
+        for label in ["user", "previous text", "assistant", "vision", "user_text"]:
+            for lf in (True, False):
+                for index in (0, 1, 2, -1, -2, 5):
+                    try:
+                        r = ref_range(t, label, index, contain_lf=lf)
+                        cases.append({"label": label, "index": index, "contain_lf": lf, "range": [int(r[0]), int(r[1])]})
+                    except IndexError:
+                        cases.append({"label": label, "index": index, "contain_lf": lf, "range": None})
+        ranges[name] = {"ids": ids, "cases": cases}
+    with open(os.path.join(OUT, "ref_qwen_ranges.json"), "w") as f:
+        json.dump(ranges, f)
+
+    class _Stub:      # get_rope_index only reads self.config.*
+        class config:
+            class vision_config:
+                spatial_merge_size = 2
+            image_token_id = 151655
+            video_token_id = VPAD
+            vision_start_token_id = VSTART
+
+    rope = {}
+    grids = {"two_rounds": [[1, 4, 4], [1, 4, 4]], "no_trailing_lf": [[1, 2, 4]], "open_assistant": [[1, 4, 2]],
+             "many_rounds": [[1, 4, 6]] * 6, "vision_first": [[1, 4, 4]]}
+    for name, g in grids.items():
+        ids = torch.tensor([seqs[name]])
+        pos, delta = ref_rope(_Stub(), ids, None, torch.tensor(g), None, torch.ones_like(ids, dtype=torch.bool))
+        rope[name] = {"ids": seqs[name], "grid": g, "pos": pos[:, 0].tolist(), "delta": int(delta.flatten()[0])}
+    # a 448x448 chunk: grid (1, 32, 32) -> 256 tokens
+    big = [IM_START, USER, LF, TIME, 28, 15, VSTART] + [VPAD] * 256 + [VEND, IM_END, LF, IM_START, ASSISTANT, LF, 5, 6]
+    ids = torch.tensor([big])
+    pos, _ = ref_rope(_Stub(), ids, None, torch.tensor([[1, 32, 32]]), None, torch.ones_like(ids, dtype=torch.bool))
+    rope["chunk_448"] = {"ids": big, "grid": [[1, 32, 32]], "pos": pos[:, 0].tolist(), "delta": 0}
+    with open(os.path.join(OUT, "ref_rope_index.json"), "w") as f:
+        json.dump(rope, f)
+    with open(os.path.join(OUT, "ref_sec2ts.json"), "w") as f:
+        json.dump({str(s): ref_sec2ts(s) for s in [0, 0.5, 1.0, 59.999, 61.25, 3600, 3661.5, 86399.001]}, f)
+    print("reference vectors: ranges", sum(len(v["cases"]) for v in ranges.values()), "cases; rope", len(rope), "sequences")
+
+
+def gen_hf_vectors():
+    """Tiny stock Qwen2-VL modules (transformers as installed) on seeded inputs.  Weights are regenerated from the
+    seed by the test (streaming_vlm_amd.weights.random_state_dict), only inputs/outputs are stored."""
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    from transformers.cache_utils import DynamicCache
+    import transformers
+    import helpers as H
+    from streaming_vlm_amd import config as C
+    from streaming_vlm_amd.weights import random_state_dict
+
+    cfg = C.tiny()
+    cfg.text.num_heads, cfg.text.num_kv_heads = 2, 1          # HF derives head_dim = hidden / heads
+    hf_cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, intermediate_size=512,
+                         vocab_size=cfg.text.vocab_size, rms_norm_eps=1e-6, tie_word_embeddings=True,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]}),
+        vision_config=dict(depth=2, embed_dim=160, num_heads=2, hidden_size=256, mlp_ratio=2, patch_size=14, temporal_patch_size=2,
+                           spatial_merge_size=2, in_channels=3),
+        tie_word_embeddings=True)
+    hf_cfg._attn_implementation = "eager"
+    model = Qwen2VLForConditionalGeneration(hf_cfg).to(torch.float32).eval()
+    sd = random_state_dict(cfg, 7, "cpu", dtype=torch.float32)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not [m for m in missing if "lm_head" not in m and "inv_freq" not in m], missing
+    assert not unexpected, unexpected
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    with torch.no_grad():
+        # ---- vision tower: 2 temporal grids of 4x4 patches
+        grid = torch.tensor([[2, 4, 4]])
+        pix = torch.randn(32, cfg.vision.patch_dim, generator=g)
+        vis = model.model.visual(pix, grid_thw=grid)
+        vis = vis.pooler_output if hasattr(vis, "pooler_output") else vis
+        out["vit_pix"], out["vit_grid"], out["vit_out"] = pix.numpy(), grid.numpy(), vis.float().numpy()
+        # ---- decoder: prefill 10 tokens then 1 token, 3-axis positions, DynamicCache
+        x = torch.randn(1, 11, 256, generator=g) * 0.5
+        pos = torch.stack([torch.arange(11), torch.tensor([0, 1, 2, 2, 2, 3, 3, 4, 5, 6, 7]), torch.tensor([0, 1, 2, 2, 3, 2, 3, 4, 5, 6, 7])]).unsqueeze(1)
+        cache = DynamicCache(config=hf_cfg.text_config) if "config" in DynamicCache.__init__.__code__.co_varnames else DynamicCache()
+        lm = model.model.language_model
+        h1 = lm(inputs_embeds=x[:, :10], position_ids=pos[:, :, :10], past_key_values=cache, use_cache=True).last_hidden_state
+        h2 = lm(inputs_embeds=x[:, 10:], position_ids=pos[:, :, 10:], past_key_values=cache, use_cache=True).last_hidden_state
+        out["lm_x"], out["lm_pos"] = x[0].numpy(), pos[:, 0].numpy()
+        out["lm_h_prefill"], out["lm_h_decode"] = h1[0].float().numpy(), h2[0].float().numpy()
+        # ---- rotary table + M-RoPE apply
+        from transformers.models.qwen2_vl import modeling_qwen2_vl as M
+        cos, sin = lm.rotary_emb(x, pos)
+        q = torch.randn(1, 2, 11, 128, generator=g)
+        k = torch.randn(1, 1, 11, 128, generator=g)
+        qe, ke = M.apply_multimodal_rotary_pos_emb(q, k, cos, sin, [16, 24, 24])
+        out["rope_cos"], out["rope_sin"] = cos[:, 0].numpy(), sin[:, 0].numpy()
+        out["rope_q"], out["rope_k"], out["rope_qe"], out["rope_ke"] = q[0].numpy(), k[0].numpy(), qe[0].numpy(), ke[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "hf_tiny_modules.npz"), **out)
+    with open(os.path.join(OUT, "hf_tiny_modules.json"), "w") as f:
+        json.dump({"transformers": transformers.__version__, "torch": torch.__version__, "weights_seed": 7, "dtype": "float32",
+                   "note": "weights = streaming_vlm_amd.weights.random_state_dict(tiny(heads=2,kv=1), seed 7, fp32)"}, f)
+    print("hf vectors:", {k: v.shape for k, v in out.items()})
+
+
+def gen_oracle_vectors():
+    import helpers as H
+    from streaming_vlm_amd import config as C
+    from streaming_vlm_amd.weights import random_state_dict
+    cfg = C.tiny()
+    sd = random_state_dict(cfg, 0, "cpu")
+    runs = {}
+    for name, kw in {
+        "sink4_win64": dict(policy="sink_window", sink=4, window=64),
+        "sink4_win256": dict(policy="sink_window", sink=4, window=256, size=112),
+        "structural_t2_v3": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+                                 previous_text="a b c d e f g h i j k l m n o p"),
+        "structural_t3_v2": dict(policy="structural", text_round=3, window_size=2, text_sink=2, text_sliding_window=6,
+                                 previous_text="a b c d e f g h i j k l m n o p"),
+        "structural_default_16": dict(policy="structural", text_round=16, window_size=16, text_sink=512, text_sliding_window=512),
+    }.items():
+        n = 20 if "default" in name else 10
+        o = H.run_oracle_stream(cfg, sd, n, **kw)
+        runs[name] = {"kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"]}
+    with open(os.path.join(OUT, "oracle_streams.json"), "w") as f:
+        json.dump(runs, f)
+    print("oracle vectors:", list(runs))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    gen_reference_vectors()
+    gen_hf_vectors()
+    gen_oracle_vectors()

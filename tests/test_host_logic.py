@@ -1,0 +1,190 @@
+"""Host logic of the product (no GPU): the engine driven by the TEST-ONLY CPU ops backend must reproduce the
+oracle's streaming loop exactly -- tokens, KV lengths, eviction traces -- and the committed oracle traces."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from ref_ops import RefOps
+
+import streaming_vlm_amd as S
+from streaming_vlm_amd import config as C
+from streaming_vlm_amd.weights import random_state_dict
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = C.tiny()
+    return cfg, random_state_dict(cfg, 0, "cpu")
+
+
+def _model(cfg, sd, **kw):
+    return S.StreamingQwen2VL(cfg, sd, "cpu", ops=RefOps(), max_len=1024, max_new_tokens=8, use_graph=False, **kw)
+
+
+def test_engine_equals_oracle_and_golden_traces(tiny, golden_dir):
+    cfg, sd = tiny
+    with open(os.path.join(golden_dir, "oracle_streams.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        if "default" in name:
+            continue
+        kw = dict(g["kwargs"])
+        res, trace, counts, log = H.run_engine_stream(_model(cfg, sd), g["n_chunks"], **kw)
+        assert [[list(t) for t in c] for c in trace] == g["trace"], name          # identical eviction indices
+        assert [e["kv_len"] for e in log] == g["kv_len"], name
+        assert [e["new"] for e in log] == g["new_tokens"], name
+        assert len(res) == g["n_chunks"] and all(isinstance(r["response"], str) for r in res)
+
+
+def test_default_structural_policy_trace(tiny, golden_dir):
+    """Reference defaults (16 vision rounds, 16 text rounds, 512+512 previous-text): trace equals the oracle's."""
+    cfg, sd = tiny
+    with open(os.path.join(golden_dir, "oracle_streams.json")) as f:
+        g = json.load(f)["structural_default_16"]
+    res, trace, counts, log = H.run_engine_stream(_model(cfg, sd), g["n_chunks"], **g["kwargs"])
+    assert [[list(t) for t in c] for c in trace] == g["trace"]
+    assert any(len(c) for c in trace), "20 chunks must trigger the 16-round eviction"
+
+
+def test_recompute_mode_equals_fresh_prefill(tiny):
+    """efficiency mode (c): no KV reuse -- every chunk re-encodes the retained frames (inference.py:423-438)."""
+    cfg, sd = tiny
+    res, trace, counts, log = H.run_engine_stream(_model(cfg, sd), 4, policy="structural", text_round=100, window_size=100, recompute=True)
+    res2, trace2, counts2, log2 = H.run_engine_stream(_model(cfg, sd), 4, policy="structural", text_round=100, window_size=100)
+    assert [e["new"] for e in log] == [e["new"] for e in log2]      # shrink mode: cached == recomputed
+
+
+def test_time_test_returns_section_times(tiny):
+    cfg, sd = tiny
+    out = S.streaming_inference(model=_model(cfg, sd), processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps",
+                                model_base="Qwen2", duration=2, do_sample=False, max_new_tokens=4, quiet=True, time_test=True)
+    assert len(out) == 2 and set(out[0]) == {"PKV", "CHECK", "VIDEO", "INPUT", "GEN", "POST"}
+
+
+def test_sampling_path_runs_and_is_seeded(tiny):
+    cfg, sd = tiny
+    outs = []
+    for _ in range(2):
+        g = torch.Generator().manual_seed(5)
+        log = []
+        S.streaming_inference(model=_model(cfg, sd), processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps",
+                              model_base="Qwen2", duration=2, do_sample=True, temperature=0.9, max_new_tokens=4, quiet=True,
+                              generator=g, ids_log=log)
+        outs.append([e["new"] for e in log])
+    assert outs[0] == outs[1]
+
+
+def test_vtt_and_json_outputs(tiny, tmp_path, capsys):
+    cfg, sd = tiny
+    p = str(tmp_path / "o.vtt")
+    S.streaming_inference(model=_model(cfg, sd), processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps", output_dir=p,
+                          model_base="Qwen2", duration=2, do_sample=False, max_new_tokens=4, quiet=True, emit_json=True)
+    txt = open(p).read()
+    assert txt.startswith("WEBVTT\n\n00:00:00.000 --> 00:00:01.000\n Infer Time:")
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert [l["type"] for l in lines] == ["segment", "segment"] and lines[1]["start"] == 1.0
+
+
+def test_error_behaviour(tiny):
+    cfg, sd = tiny
+    m = _model(cfg, sd)
+    with pytest.raises(AssertionError):
+        S.streaming_inference(model=m, processor=S.SyntheticProcessor(), window_size=5, chunk_duration=2, video_path="synthetic://56x56@1fps")
+    with pytest.raises(FileNotFoundError):
+        S.streaming_inference(model=m, processor=S.SyntheticProcessor(), video_path="/no/such/video.mp4", model_base="Qwen2", quiet=True)
+    with pytest.raises(NotImplementedError):
+        S.streaming_inference(model=m, processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps", pos_mode="append",
+                              model_base="Qwen2", duration=1, quiet=True)
+    with pytest.raises(ValueError):       # pixel/token mismatch is the reference's ValueError (model_forward.py:56-61)
+        m._svlm_engine.generate([151652, 151656, 151653, 5], None, [[1, 4, 4]], torch.zeros(16, 1176), [[1, 4, 4]], max_new_tokens=2)
+    with pytest.raises(MemoryError):
+        m._svlm_engine.generate(list(range(10, 1100)), None, [], max_new_tokens=2)
+
+
+# ----------------------------------------------------------------------------- KV pool
+def _pool(max_len=256, pages=16):
+    return S.KVPool(2, 2, 128, max_len, "cpu", RefOps(), page_tokens=pages, slack=0.25)
+
+
+def _fill(pool, n, base):
+    start = pool.length
+    pool.reserve(n)
+    k = torch.arange(base, base + n, dtype=torch.float32).view(n, 1).expand(n, 256).to(torch.bfloat16).contiguous()
+    for layer in range(2):
+        pool.ops.kv_append(k, -k, pool.pool, layer, torch.from_numpy(pool.slot_of), start, n)
+    pool.commit(start + n)
+
+
+def _rows(pool, layer=0):
+    pool_k, pool_v = pool.layer_kv(layer)
+    return pool_k[0, 0, :, 0].float().tolist(), pool_v[0, 1, :, 5].float().tolist()
+
+
+def test_pool_prune_move_truncate_match_list_semantics():
+    pool = _pool()
+    pool.slot_of_dev = torch.from_numpy(pool.slot_of)      # CPU "device" mirror shares memory
+    _fill(pool, 100, 0)
+    ref = list(range(100))
+    pool.prune(4, 23); del ref[4:24]
+    pool.move(50, 56, 10); ref = ref[:11] + ref[50:57] + ref[11:50] + ref[57:]
+    pool.truncate(70); ref = ref[:70]
+    _fill(pool, 30, 130); ref += list(range(130, 160))       # bf16 holds integers < 256 exactly
+    k, v = _rows(pool)
+    assert k == [float(r) for r in ref] and v == [-float(r) for r in ref]
+    assert pool.get_seq_length() == 100 and len(list(iter(pool))) == 2
+
+
+def test_pool_frees_pages_and_defragments_in_place():
+    pool = _pool(max_len=256, pages=16)
+    pool.slot_of_dev = torch.from_numpy(pool.slot_of)
+    _fill(pool, 240, 0)
+    free0 = pool.free_slots_available()
+    keep = list(range(240))
+    # evict 12 of every 16 rows -> every page keeps 4 live rows (pinned, fragmented)
+    for p in reversed(range(15)):
+        pool.prune(p * 16 + 2, p * 16 + 13)
+        del keep[p * 16 + 2:p * 16 + 14]
+    assert pool.fragmentation() > 0.5 and pool.free_slots_available() == free0
+    moved = pool.defragment()
+    assert moved > 0 and pool.free_slots_available() > free0 and pool.stats["defrags"] == 1
+    k, v = _rows(pool, 1)
+    assert k == [float(r) for r in keep] and v == [-float(r) for r in keep]
+    # reserve() defragments on demand instead of failing
+    pool2 = _pool(max_len=256, pages=16)
+    pool2.slot_of_dev = torch.from_numpy(pool2.slot_of)
+    _fill(pool2, 250, 0)
+    for p in reversed(range(15)):
+        pool2.prune(p * 16 + 1, p * 16 + 14)
+    _fill(pool2, 150, 1000)
+    assert pool2.length == 250 - 15 * 14 + 150
+
+
+def test_pool_limits():
+    pool = _pool(max_len=64)
+    with pytest.raises(MemoryError):
+        pool.reserve(65)
+    pool.reserve(10)
+    with pytest.raises(AssertionError):
+        pool.prune(0, 3)             # reserved-but-uncommitted rows must be released first
+    pool.release_reserved()
+    assert pool.reserved == 0
+
+
+def test_patchify_matches_hf_layout():
+    """Row order must be merge-block-major (what the merger's view(-1, 4*embed) relies on)."""
+    frames = torch.arange(2 * 3 * 28 * 56, dtype=torch.float32).reshape(2, 3, 28, 56).to(torch.uint8)
+    pix, grid = S.patchify(frames)
+    assert grid == [[1, 2, 4]] and tuple(pix.shape) == (8, 1176)
+    x = frames.float() / 255.0
+    mean = torch.tensor(S.synthetic.OPENAI_CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(S.synthetic.OPENAI_CLIP_STD).view(1, 3, 1, 1)
+    x = (x - mean) / std
+    # patch (h=1, w=2) is row 4*? in merge-block-major order: blocks (0,0):[(0,0),(0,1),(1,0),(1,1)], (0,1):[(0,2),(0,3),(1,2),(1,3)]
+    want = x[:, :, 14:28, 28:42].permute(1, 0, 2, 3).reshape(-1)          # (C, T, P, P) flattening of patch (1, 2)
+    assert torch.allclose(pix[6], want)
+    one, g1 = S.patchify(frames[:1])                                        # a single frame is duplicated to fill the temporal patch
+    assert g1 == [[1, 2, 4]] and torch.allclose(one[:, :], S.patchify(torch.cat([frames[:1], frames[:1]]))[0])
