@@ -28,91 +28,6 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
-class TimedOps:
-    """Wraps HipOps: every launch is bracketed by HIP events on the launching stream and tagged with its
-    algorithmic bytes / flops (formulas in DESIGN.md 'Kernels and rooflines')."""
-
-    def __init__(self, ops):
-        self._ops = ops
-        self.records = []
-        self.name = "hip-timed"
-
-    def decode_attn_ws(self, *a, **k):
-        return self._ops.decode_attn_ws(*a, **k)
-
-    def _run(self, kernel, nbytes, flops, fn, *a, **k):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        r = fn(*a, **k)
-        e.record()
-        self.records.append((kernel, nbytes, flops, s, e))
-        return r
-
-    def gemm(self, A, W, bias=None, residual=None, out=None, act=0):
-        M, K = A.shape
-        N = W.shape[0]
-        nb = 2 * (M * K + N * K + M * N * (2 if residual is not None else 1))
-        return self._run("gemm_bf16_kernel", nb, 2.0 * M * N * K, self._ops.gemm, A, W, bias, residual, out, act)
-
-    def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=0):
-        N, K = W.shape
-        nb = 2 * (N * K + K + N * (2 if residual is not None else 1)) + (4 * N if out_f32 is not None else 0)
-        return self._run("gemv_bf16_kernel", nb, 2.0 * N * K, self._ops.gemv, x, W, bias, residual, out, out_f32, act)
-
-    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
-        N, K = W.shape
-        return self._run("dec_qkv_kernel", 2 * (N * K + 2 * K + 2 * N), 2.0 * N * K, self._ops.dec_qkv, x, ln_w, eps, W, bias, q_out,
-                         pool, layer, slot_of, qd, kd, length, len_dev)
-
-    def dec_gate_up(self, x, ln_w, eps, W, h):
-        N, K = W.shape
-        return self._run("dec_gate_up_kernel", 2 * (N * K + 2 * K + N // 2), 2.0 * N * K, self._ops.dec_gate_up, x, ln_w, eps, W, h)
-
-    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws):
-        N, K = W.shape
-        return self._run("dec_lm_head_kernel", 2 * (N * K + 2 * K) + 5 * N, 2.0 * N * K, self._ops.dec_lm_head, x, ln_w, eps, W, logits,
-                         seen, penalty, suppress, ws)
-
-    def sampling_ws(self, *a, **k):
-        return self._ops.sampling_ws(*a, **k)
-
-    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None):
-        _, _, Hkv, _, D = pool.shape
-        L = (int(len_dev[0]) if len_dev is not None else 0) + length     # host read: instrumented pass only
-        nb = 2 * L * Hkv * D * 2 + L * 3 * 4 + 2 * Hq * D * 2 + 2 * Hkv * D * 2
-        return self._run("decode_attn_split_kernel", nb, 4.0 * L * Hq * D, self._ops.decode_attn, q, pool, layer, slot_of, rope_cs,
-                         out, ws, Hq, max_len, chunk, scale, length, len_dev)
-
-    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale):
-        _, _, Hkv, _, D = pool.shape
-        nb = 2 * L * Hkv * D * 2 + 2 * T * Hq * D * 2
-        return self._run("flash_attn_kernel(prefill)", nb, 4.0 * T * (L - T / 2.0) * Hq * D, self._ops.prefill_attn, q, pool, layer,
-                         slot_of, rope_cs, out, T, L, Hq, scale)
-
-    def vit_attn(self, qkv, n_seq, seq_len, H, d, scale, out=None):
-        N = qkv.shape[0]
-        return self._run("flash_attn_kernel(vit)", 2 * N * 4 * H * d, 4.0 * n_seq * seq_len * seq_len * H * d, self._ops.vit_attn,
-                         qkv, n_seq, seq_len, H, d, scale, out)
-
-    def __getattr__(self, name):
-        fn = getattr(self._ops, name)
-
-        def wrapped(*a, **k):
-            return self._run(name, 0, 0.0, fn, *a, **k)
-        return wrapped
-
-    def summary(self):
-        torch.cuda.synchronize()
-        agg = {}
-        for kernel, nb, fl, s, e in self.records:
-            a = agg.setdefault(kernel, dict(launches=0, ms=0.0, bytes=0, flops=0.0))
-            a["launches"] += 1
-            a["ms"] += s.elapsed_time(e)
-            a["bytes"] += nb
-            a["flops"] += fl
-        return agg
-
-
 _T0 = time.perf_counter()
 
 
@@ -164,6 +79,8 @@ def main():
 
     t = {}
     counts = []
+    kvlog = []
+    kv_steady = [args.sink + args.window]
 
     def fence():
         MS.fence(dist, dev)
@@ -178,8 +95,10 @@ def main():
 
     S.streaming_inference(model=model, processor=proc, video=video, model_base="Qwen2", duration=n_chunks, previous_text="",
                           kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=False,
-                          max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk)
+                          max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk,
+                          ids_log=kvlog)
     fence()
+    kv_steady[0] = kvlog[-1]["kv_len"]
     elapsed = time.perf_counter() - t["t0"]
     log(f"timed region done: {elapsed:.3f} s for {args.steps} chunks")
     frames = args.steps * frames_per_chunk
@@ -194,14 +113,14 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{cfg.name} bf16, {args.size}x{args.size} @{args.fps:g}fps synthetic stream, KV sink={args.sink} "
                                f"window={args.window}, {args.new_tokens} greedy tokens/chunk, one stream per GPU",
-                   "frames_per_chunk": frames_per_chunk, "new_tokens_per_chunk": args.new_tokens, "kv_len_steady": None,
+                   "frames_per_chunk": frames_per_chunk, "new_tokens_per_chunk": args.new_tokens, "kv_len_steady": kv_steady[0],
                    "parallelism": f"streams{world}"},
         "per_gpu_frames_per_sec": [round(v, 3) for v in per_gpu_fps],
     }
 
     if rank == 0 and not args.no_roofline:
         log("roofline pass (eager launches bracketed by HIP events)")
-        out.update(roofline_pass(model, proc, video, args, n_chunks))
+        out.update(roofline_pass(model, args, kv_steady[0]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline (oracle on host cores)")
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args)
@@ -212,61 +131,158 @@ def main():
         print(json.dumps(out), flush=True)
 
 
-def roofline_pass(model, proc, video, args, n_chunks):
-    """Re-run the last chunk's generate with eager launches bracketed by HIP events (same operands, weights
-    cold in HBM: 3 GB of weights per token never fit the 256 MiB Infinity Cache)."""
-    import streaming_vlm_amd as S
-    eng = model._svlm_engine
-    timed = TimedOps(eng.ops)
-    real_ops, real_graph = eng.ops, eng.use_graph
-    counts = []
-    # a fresh short stream at steady-state length: warm the cache with untimed chunks, then time 2 chunks eagerly
-    fill = max(2, (args.sink + args.window) // ((args.size // 28) ** 2 + 40) + 2)
-    fill = min(fill, n_chunks - 2)
+def roofline_pass(model, args, kv_len):
+    """Per-kernel durations measured live with HIP events on the launching stream, on the model's real operands.
 
-    def on_chunk(i):
-        if i == fill:
+    Each kernel symbol is launched back-to-back over ALL layers (every launch streams different weights / a
+    different layer's KV, as in the real step) between ONE event pair, after a 512 MiB write that evicts L2 and
+    the 256 MiB Infinity Cache; avg launch = elapsed / launches.  (Bracketing every single launch with its own
+    event pair adds ~7 us of event latency per kernel -- more than most of these kernels take.)
+    Algorithmic bytes / flops per launch are the formulas of DESIGN.md 'Kernels and rooflines'."""
+    import math
+    eng = model._svlm_engine
+    o, w, cfg = eng.ops, eng.w, eng.cfg
+    tc, vc = cfg.text, cfg.vision
+    dev = eng.device
+    H, I, V, D = tc.hidden_size, tc.intermediate_size, tc.vocab_size, tc.head_dim
+    Hq, Hkv, qd, kd, NL = tc.num_heads, tc.num_kv_heads, eng.qd, eng.kd, tc.num_layers
+    L = int(kv_len)
+    T = (args.size // 28) ** 2 + 19                      # prefill rows of a steady-state chunk
+    n_dec = args.new_tokens - 1
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    c = eng.new_cache()
+    c.reserve(L + 1)
+    c.commit(L)
+    c.sync_device()
+    pos = torch.arange(L + 1, dtype=torch.int32, device=dev).repeat(3, 1)
+    eng.pos3_dev[:, :L + 1].copy_(pos)
+    o.mrope_table(eng.pos3_dev, eng.inv_freq, eng.rope_cs, 0, L + 1, tc.mrope_section)
+    eng.state.copy_(torch.tensor([L, 0], dtype=torch.int32))
+    kv_dev = eng.state[0:1]
+    scale = 1.0 / math.sqrt(D)
+    results = []
+
+    def timed(name, launches, per_chunk, nbytes, flops, fn, reps=3):
+        best = None
+        for _ in range(reps):
+            flush.fill_(1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
             torch.cuda.synchronize()
-            eng.ops, eng.use_graph = timed, False
-            eng._graph = None
-    try:
-        kvlog = []
-        S.streaming_inference(model=model, processor=proc, video=video, model_base="Qwen2", duration=fill + 2, previous_text="",
-                              kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=False,
-                              max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts,
-                              chunk_callback=on_chunk, ids_log=kvlog)
-    finally:
-        eng.ops, eng.use_graph = real_ops, real_graph
-        eng._graph = None
-    agg = timed.summary()
-    kernels = []
-    for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
-        if a["launches"] == 0:
-            continue
-        us = 1e3 * a["ms"] / a["launches"]
-        k = {"kernel": name, "launches": a["launches"], "total_ms": round(a["ms"], 3), "avg_us": round(us, 2)}
-        if a["bytes"]:
-            k["GBps"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
-        if a["flops"]:
-            k["TFLOPs"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2)
-        kernels.append(k)
-    dom = kernels[0]
-    mfma_bound = dom["kernel"].startswith("gemm") or dom["kernel"].startswith("flash")
-    if mfma_bound:
-        ach = dom.get("TFLOPs", 0.0)
-        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+            ms = s.elapsed_time(e)
+            best = ms if best is None else min(best, ms)
+        us = 1e3 * best / launches
+        r = {"kernel": name, "avg_us": round(us, 2), "launches_per_chunk": per_chunk, "ms_per_chunk": round(us * per_chunk / 1e3, 3)}
+        if nbytes:
+            r["bytes_per_launch"] = int(nbytes)
+            r["GBps"] = round(nbytes / us / 1e3, 1)
+        if flops:
+            r["TFLOPs"] = round(flops / us / 1e6, 2)
+        results.append(r)
+
+    lw = w.layers
+    # ---- decode-step kernels (T = 1)
+    timed("dec_qkv_kernel", NL, NL * n_dec, 2 * ((qd + 2 * kd) * H + 2 * H + 2 * (qd + 2 * kd)), 2.0 * (qd + 2 * kd) * H,
+          lambda: [o.dec_qkv(eng.d_x, l["ln1"], tc.rms_eps, l["qkv_w"], l["qkv_b"], eng.d_qkv, c.pool, i, c.slot_of_dev, qd, kd, len_dev=kv_dev)
+                   for i, l in enumerate(lw)])
+    attn_bytes = 2 * (L + 1) * Hkv * D * 2 + (L + 1) * 3 * 4 + 2 * Hq * D * 2 + 2 * Hkv * D * 2
+    timed("decode_attn_split_kernel+decode_attn_combine_kernel", NL, NL * n_dec, attn_bytes, 4.0 * (L + 1) * Hq * D,
+          lambda: [o.decode_attn(eng.d_qkv[:qd], c.pool, i, c.slot_of_dev, eng.rope_cs, eng.d_attn, eng.d_ws, Hq, eng.max_len,
+                                 eng.decode_chunk, scale, length=1, len_dev=kv_dev) for i in range(NL)])
+    timed("gemv_bf16_kernel(o_proj)", NL, NL * n_dec, 2 * (H * qd + qd + 2 * H), 2.0 * H * qd,
+          lambda: [o.gemv(eng.d_attn, l["o_w"], residual=eng.d_x, out=eng.d_x) for l in lw])
+    timed("dec_gate_up_kernel", NL, NL * n_dec, 2 * (2 * I * H + 2 * H + I), 4.0 * I * H,
+          lambda: [o.dec_gate_up(eng.d_x, l["ln2"], tc.rms_eps, l["gu_w"], eng.d_h) for l in lw])
+    timed("gemv_bf16_ksplit_kernel(down_proj)", NL, NL * n_dec, 2 * (H * I + I + 2 * H), 2.0 * H * I,
+          lambda: [o.gemv(eng.d_h, l["down_w"], residual=eng.d_x, out=eng.d_x) for l in lw])
+    timed("dec_lm_head_kernel", 1, n_dec, 2 * (V * H + 2 * H) + 5 * V, 2.0 * V * H,
+          lambda: o.dec_lm_head(eng.d_x, w.final_norm, tc.rms_eps, w.lm_head, eng.logits, eng.seen, 1.05, None, eng.d_sws))
+    # ---- prefill (T rows) and ViT (N patches) MFMA kernels
+    x = torch.randn((T, H), device=dev).to(torch.bfloat16)
+    qkv = torch.empty((T, qd + 2 * kd), dtype=torch.bfloat16, device=dev)
+    att = torch.randn((T, qd), device=dev).to(torch.bfloat16)
+    gu = torch.empty((T, 2 * I), dtype=torch.bfloat16, device=dev)
+    hm = torch.randn((T, I), device=dev).to(torch.bfloat16)
+    gflops = lambda M, N, K: 2.0 * M * N * K
+    gbytes = lambda M, N, K: 2 * (M * K + N * K + M * N)
+
+    def llm_gemms():
+        for l in lw:
+            o.gemm(x, l["qkv_w"], bias=l["qkv_b"], out=qkv)
+            o.gemm(att, l["o_w"], residual=x, out=x)
+            o.gemm(x, l["gu_w"], out=gu)
+            o.gemm(hm, l["down_w"], residual=x, out=x)
+    fl = gflops(T, qd + 2 * kd, H) + gflops(T, H, qd) + gflops(T, 2 * I, H) + gflops(T, H, I)
+    by = gbytes(T, qd + 2 * kd, H) + gbytes(T, H, qd) + gbytes(T, 2 * I, H) + gbytes(T, H, I)
+    timed("gemm_bf16_kernel(prefill: qkv,o,gate_up,down)", 4 * NL, 4 * NL, by / 4, fl / 4, llm_gemms)
+    c2 = eng.new_cache()
+    Lp = min(L + T, eng.max_len)
+    c2.reserve(Lp)
+    c2.commit(Lp)
+    c2.sync_device()
+    timed("rope_gather_kernel+flash_attn_kernel<128,128>(prefill)", NL, NL, 2 * Lp * Hkv * D * 2 * 2 + 2 * T * Hq * D * 2,
+          4.0 * T * (Lp - T / 2.0) * Hq * D,
+          lambda: [o.prefill_attn(qkv[:, :qd], c2.pool, i, c2.slot_of_dev, eng.rope_cs, att, T, Lp, Hq, scale) for i in range(NL)])
+    N = (args.size // 14) ** 2
+    E, Hh, dv, F = vc.embed_dim, vc.num_heads, vc.head_dim, vc.mlp_hidden
+    xv = torch.randn((N, E), device=dev).to(torch.bfloat16)
+    qv = torch.randn((N, 3 * E), device=dev).to(torch.bfloat16)
+    av = torch.randn((N, E), device=dev).to(torch.bfloat16)
+    fv = torch.randn((N, F), device=dev).to(torch.bfloat16)
+
+    def vit_gemms():
+        for b in w.vit:
+            o.gemm(xv, b["qkv_w"], bias=b["qkv_b"], out=qv)
+            o.gemm(av, b["proj_w"], bias=b["proj_b"], residual=xv, out=xv)
+            o.gemm(xv, b["fc1_w"], bias=b["fc1_b"], out=fv, act=1)
+            o.gemm(fv, b["fc2_w"], bias=b["fc2_b"], residual=xv, out=xv)
+    fl = gflops(N, 3 * E, E) + gflops(N, E, E) + 2 * gflops(N, F, E)
+    by = gbytes(N, 3 * E, E) + gbytes(N, E, E) + 2 * gbytes(N, F, E)
+    timed("gemm_bf16_kernel(vit: qkv,proj,fc1,fc2)", 4 * vc.depth, 4 * vc.depth, by / 4, fl / 4, vit_gemms)
+    timed(f"flash_attn_kernel<{dv},{96 if dv == 80 else dv}>(vit)", vc.depth, vc.depth, 2 * N * 4 * Hh * dv, 4.0 * N * N * Hh * dv,
+          lambda: [o.vit_attn(qv, 1, N, Hh, dv, 1.0 / math.sqrt(dv), out=av) for _ in range(vc.depth)])
+
+    results.sort(key=lambda r: -r["ms_per_chunk"])
+    dom = results[0]
+    if "flash" in dom["kernel"] or dom["kernel"].startswith("gemm"):
+        roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": dom.get("TFLOPs"), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(dom.get("TFLOPs", 0.0) / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
     else:
-        ach = dom.get("GBps", 0.0)
-        roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-    roof["avg_launch_us"] = dom["avg_us"]
-    roof["launches"] = dom["launches"]
-    da = next((k for k in kernels if k["kernel"].startswith("decode_attn")), None)
-    extra = {"roofline": roof, "kernels": kernels[:12], "kv_len_timed": kvlog[-1]["kv_len"] if kvlog else None}
-    if da is not None:
-        extra["roofline_decode_attn"] = {"bound": "hbm", "achieved": da.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(da.get("GBps", 0.0) / HBM_PEAK_GBS, 4), "avg_launch_us": da["avg_us"]}
+        roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom.get("GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(dom.get("GBps", 0.0) / HBM_PEAK_GBS, 4), "traffic": None}
+    roof.update(avg_launch_us=dom["avg_us"], algorithmic_bytes_per_launch=dom.get("bytes_per_launch"), launches_per_chunk=dom["launches_per_chunk"])
+    da = next(r for r in results if r["kernel"].startswith("decode_attn"))
+    extra = {"roofline": roof, "kernels": results, "kv_len_timed": L,
+             "roofline_decode_attn": {"bound": "hbm", "achieved": da["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(da["GBps"] / HBM_PEAK_GBS, 4), "avg_launch_us": da["avg_us"],
+                                      "algorithmic_bytes_per_launch": da["bytes_per_launch"], "kv_len": L + 1}}
+    # long-window point (mode (a) "full attention" regime): the same kernel where it is genuinely bandwidth-bound
+    try:
+        Lbig = 32768
+        eng2_len = Lbig + 64
+        pool = torch.zeros((1, 2, Hkv, eng2_len, D), dtype=torch.bfloat16, device=dev)
+        slot = torch.arange(eng2_len, dtype=torch.int32, device=dev)
+        rope = torch.zeros((eng2_len, D), dtype=torch.bfloat16, device=dev)
+        ws = o.decode_attn_ws(Hq, eng2_len, 64, dev)
+        out = torch.empty(qd, dtype=torch.bfloat16, device=dev)
+        qq = torch.randn(qd, device=dev).to(torch.bfloat16)
+        best = None
+        for _ in range(3):
+            flush.fill_(1)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            o.decode_attn(qq, pool, 0, slot, rope, out, ws, Hq, eng2_len, 64, scale, length=Lbig)
+            e.record()
+            torch.cuda.synchronize()
+            best = s.elapsed_time(e) if best is None else min(best, s.elapsed_time(e))
+        nb = 2 * Lbig * Hkv * D * 2 + Lbig * 3 * 4
+        extra["roofline_decode_attn_32k"] = {"kv_len": Lbig, "avg_launch_us": round(best * 1e3, 2), "achieved": round(nb / best / 1e6, 1),
+                                             "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(nb / best / 1e6 / HBM_PEAK_GBS, 4),
+                                             "algorithmic_bytes_per_launch": nb}
+    except Exception as ex:          # measurement extra only
+        extra["roofline_decode_attn_32k"] = {"error": str(ex)}
     return extra
 
 
