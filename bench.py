@@ -135,8 +135,9 @@ def roofline_pass(model, args, kv_len):
     """Per-kernel durations measured live with HIP events on the launching stream, on the model's real operands.
 
     Each kernel symbol is launched back-to-back over ALL layers (every launch streams different weights / a
-    different layer's KV, as in the real step) between ONE event pair, after a 512 MiB write that evicts L2 and
-    the 256 MiB Infinity Cache; avg launch = elapsed / launches.  (Bracketing every single launch with its own
+    different layer's KV, as in the real step) from a captured HIP graph between ONE event pair, after a 512 MiB
+    write that evicts L2 and the 256 MiB Infinity Cache; avg launch = elapsed / launches (includes the ~1 us
+    kernel-to-kernel boundary, like the real decode graph).  (Bracketing every single launch with its own
     event pair adds ~7 us of event latency per kernel -- more than most of these kernels take.)
     Algorithmic bytes / flops per launch are the formulas of DESIGN.md 'Kernels and rooflines'."""
     import math
@@ -163,12 +164,17 @@ def roofline_pass(model, args, kv_len):
     results = []
 
     def timed(name, launches, per_chunk, nbytes, flops, fn, reps=3):
+        fn()                                     # warm: lazy workspaces are allocated outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()               # replay from a HIP graph: Python cannot launch 5-us kernels back-to-back
+        with torch.cuda.graph(g):
+            fn()
         best = None
         for _ in range(reps):
             flush.fill_(1)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            fn()
+            g.replay()
             e.record()
             torch.cuda.synchronize()
             ms = s.elapsed_time(e)
