@@ -21,8 +21,8 @@
 //                                            so softmax stats, P and O never leave the lane)
 // The k-slot <-> key mapping of the second product is the permutation that makes the S^T
 // accumulator registers a valid B fragment; V^T is read with the same permutation.
-// Pipeline: two LDS stages; the global loads of key tile t+2 are issued before tile t is computed and
-// written to LDS one iteration later, one barrier per 32-key tile.
+// Pipeline: two LDS stages + a two-slot register ring; the global loads of key tile t+3 are issued while tile t is
+// computed (two iterations to land), one barrier per 32-key tile.
 #include "common.h"
 
 #define FA_KT 32        // keys per tile
@@ -88,9 +88,10 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   if (causal) kmax = min(L, min(blockIdx.x * 64 + 63, T - 1) + causal_offset + 1);
   const int n_kt = (kmax + FA_KT - 1) / FA_KT;
 
-  // ---- staging: thread owns chunks idx = tid + i*256 of every tile
-  u32x4_t kreg[NCH], vreg[NCH];
-  auto load_tile = [&](int kt) {
+  // ---- staging: thread owns chunks idx = tid + i*256 of every tile; two register slots form a ring so that the
+  // global loads of tile t+3 are in flight while tile t is computed (one barrier per tile, two iterations to land)
+  u32x4_t kr0[NCH], vr0[NCH], kr1[NCH], vr1[NCH];
+  auto load_tile = [&](int kt, u32x4_t (&kreg)[NCH], u32x4_t (&vreg)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int idx = tid + i * FA_THREADS;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       vreg[i] = ok ? *reinterpret_cast<const u32x4_t*>(v + (size_t)j * kv_row_stride + c * 8) : u32x4_t{0, 0, 0, 0};
     }
   };
-  auto store_tile = [&](int st) {
+  auto store_tile = [&](int st, const u32x4_t (&kreg)[NCH], const u32x4_t (&vreg)[NCH]) {
     bf16_t* ks_ = Ks + st * KS_STAGE;
     bf16_t* vt_ = Vt + st * VT_STAGE;
 #pragma unroll
@@ -115,19 +116,9 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     }
   };
 
-  load_tile(0);
-  __syncthreads();          // pad zeroing visible before the first K store lands next to it
-  store_tile(0);
-  load_tile(1);
-  __syncthreads();
-
-  for (int kt = 0; kt < n_kt; ++kt) {
-    const int st = kt & 1;
-    if (kt + 1 < n_kt) store_tile(st ^ 1);      // stage st^1 was last read in iteration kt-1 (barrier passed)
-    load_tile(kt + 2);
+  auto compute = [&](int kt, int st) {
     const bf16_t* ks_ = Ks + st * KS_STAGE;
     const bf16_t* vt_ = Vt + st * VT_STAGE;
-
     // ---- S^T = K . Q^T   (two 16-key sub-tiles)
     f32x4_t sacc[2];
 #pragma unroll
@@ -181,6 +172,25 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
       oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
     }
+  };
+
+  load_tile(0, kr0, vr0);
+  load_tile(1, kr1, vr1);
+  __syncthreads();          // pad zeroing visible before the first K store lands next to it
+  store_tile(0, kr0, vr0);
+  load_tile(2, kr0, vr0);
+  __syncthreads();
+  for (int kt = 0; kt < n_kt; kt += 2) {
+    // even: stage 0 holds tile kt; slot 1 holds kt+1, slot 0 holds kt+2
+    if (kt + 1 < n_kt) store_tile(1, kr1, vr1);
+    load_tile(kt + 3, kr1, vr1);
+    compute(kt, 0);
+    __syncthreads();
+    if (kt + 1 >= n_kt) break;
+    // odd: stage 1 holds tile kt+1; slot 0 holds kt+2, slot 1 holds kt+3
+    if (kt + 2 < n_kt) store_tile(0, kr0, vr0);
+    load_tile(kt + 4, kr0, vr0);
+    compute(kt + 1, 1);
     __syncthreads();
   }
 

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ bias,
                                                         const bf16_t* residual, int ldr,
                                                         bf16_t* C, int ldc, float* __restrict__ partial,
-                                                        int M, int N, int K, int k_per_split, int act) {
+                                                        int M, int N, int K, int k_per_split, int act, int gm, int gn, int splits) {
   constexpr int BM = 32 * TM;
   constexpr int A_PASSES = BM / 32;
   constexpr int W_PASSES = GEMM_BN / 32;
@@ -39,9 +39,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * GEMM_BN;
+  // ---- workgroup -> (tile, K-split).  Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each), so
+  // bid % 8 names the XCD group.  Speed only, never correctness:
+  //   split-K : the split index varies fastest -> an XCD only ever touches ONE K-slice of A and W (fits its L2)
+  //   no split: each XCD owns a contiguous range of n-tiles and walks m fastest -> a W tile is fetched once and
+  //             reused by all m-tiles from L2, the (smaller) A panel is what gets re-streamed
+  const int bid = blockIdx.x;
+  int tm, tn, split;
+  if (splits > 1) {
+    split = bid % splits;
+    const int t = bid / splits;
+    tn = t % gn;
+    tm = t / gn;
+  } else {
+    split = 0;
+    const int npx = (gn + 7) / 8;
+    const int local = bid / 8;
+    tn = (bid % 8) * npx + local / gm;
+    tm = local % gm;
+    if (tn >= gn) return;          // whole workgroup: the grid is padded to 8 * npx * gm
+  }
+  const int m0 = tm * BM, n0 = tn * GEMM_BN;
   const int lrow = tid >> 3, lchunk = tid & 7;  // loader: 8 threads cover one 128-B row segment
-  const int k_begin = blockIdx.z * k_per_split;
+  const int k_begin = split * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
   const int nk = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
 
@@ -128,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       const int n = n0 + wn * 64 + j * 16 + fq * 4;
       if (n >= N) continue;
       if (partial) {  // split-K: raw fp32 slab, the epilogue runs in the reduce kernel
-        *reinterpret_cast<f32x4_t*>(partial + ((size_t)blockIdx.z * M + m) * N + n) = acc[i][j];
+        *reinterpret_cast<f32x4_t*>(partial + ((size_t)split * M + m) * N + n) = acc[i][j];
         continue;
       }
       float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
@@ -215,7 +235,8 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
     splits = (K + kps - 1) / kps;
   }
   float* partial = splits > 1 ? (float*)ws : nullptr;
-  dim3 grid(gn, gm, splits);
+  const int nblocks = splits > 1 ? gn * gm * splits : 8 * ((gn + 7) / 8) * gm;
+  dim3 grid(nblocks, 1, 1);
   // LDS: two stages of (BM + 128) rows x 144 B -- above the 64 KB default for TM = 4, so opt in once
   constexpr int LDS2 = 2 * (64 + GEMM_BN) * GEMM_LD * 2, LDS4 = 2 * (128 + GEMM_BN) * GEMM_LD * 2;
   static bool attr_done = false;
@@ -230,10 +251,10 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
   }
   if (small) {
     gemm_bf16_kernel<2><<<grid, 256, LDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
-                                             (bf16_t*)C, ldc, partial, M, N, K, kps, act);
+                                             (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
   } else {
     gemm_bf16_kernel<4><<<grid, 256, LDS4, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
-                                             (bf16_t*)C, ldc, partial, M, N, K, kps, act);
+                                             (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
   }
   int rc = svlm_check_launch("svlm_gemm_bf16");
   if (rc || splits == 1) return rc;
