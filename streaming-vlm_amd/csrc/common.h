@@ -52,6 +52,12 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT.  __syncthreads() carries a release fence
+// for which hipcc emits s_waitcnt vmcnt(0) (gfx950 counts loads and stores on one counter), draining a software
+// prefetch ring at every K-tile; here only this wave's LDS traffic is waited for.  The asm memory clobber keeps
+// the compiler from moving LDS/global accesses across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // activation codes shared with include/svlm.h
 #define SVLM_ACT_NONE 0
 #define SVLM_ACT_QUICK_GELU 1

@@ -96,22 +96,26 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     for (int i = 0; i < NCH; ++i) {
       const int idx = tid + i * FA_THREADS;
       const int row = idx / CPR, c = idx % CPR;
-      const int j = kt * FA_KT + row;
-      const bool ok = idx < FA_KT * CPR && kt < n_kt && j < L;
-      kreg[i] = ok ? *reinterpret_cast<const u32x4_t*>(k + (size_t)j * kv_row_stride + c * 8) : u32x4_t{0, 0, 0, 0};
-      vreg[i] = ok ? *reinterpret_cast<const u32x4_t*>(v + (size_t)j * kv_row_stride + c * 8) : u32x4_t{0, 0, 0, 0};
+      // unconditional loads from clamped addresses + select (predicated loads become branches and make hipcc drain the
+      // register ring with vmcnt(0))
+      const int j = kt * FA_KT + (idx < FA_KT * CPR ? row : 0);
+      const size_t off = (size_t)min(j, L - 1) * kv_row_stride + (idx < FA_KT * CPR ? c : 0) * 8;
+      kreg[i] = *reinterpret_cast<const u32x4_t*>(k + off);       // rows >= L are zeroed when the tile is stored
+      vreg[i] = *reinterpret_cast<const u32x4_t*>(v + off);
     }
   };
-  auto store_tile = [&](int st, const u32x4_t (&kreg)[NCH], const u32x4_t (&vreg)[NCH]) {
+  auto store_tile = [&](int st, int kt, const u32x4_t (&kreg)[NCH], const u32x4_t (&vreg)[NCH]) {
     bf16_t* ks_ = Ks + st * KS_STAGE;
     bf16_t* vt_ = Vt + st * VT_STAGE;
+    const u32x4_t z = u32x4_t{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int idx = tid + i * FA_THREADS;
       if (idx < FA_KT * CPR) {
         const int row = idx / CPR, c = idx % CPR;
-        *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = kreg[i];
-        *reinterpret_cast<u32x4_t*>(vt_ + row * FA_VLD + c * 8) = vreg[i];      // V stays row-major: transposed on read
+        const bool ok = kt * FA_KT + row < L;
+        *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = ok ? kreg[i] : z;
+        *reinterpret_cast<u32x4_t*>(vt_ + row * FA_VLD + c * 8) = ok ? vreg[i] : z;      // V stays row-major: transposed on read
       }
     }
   };
@@ -177,21 +181,23 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   load_tile(0, kr0, vr0);
   load_tile(1, kr1, vr1);
   __syncthreads();          // pad zeroing visible before the first K store lands next to it
-  store_tile(0, kr0, vr0);
+  store_tile(0, 0, kr0, vr0);
   load_tile(2, kr0, vr0);
   __syncthreads();
   for (int kt = 0; kt < n_kt; kt += 2) {
     // even: stage 0 holds tile kt; slot 1 holds kt+1, slot 0 holds kt+2
-    if (kt + 1 < n_kt) store_tile(1, kr1, vr1);
+    if (kt + 1 < n_kt) store_tile(1, kt + 1, kr1, vr1);
     load_tile(kt + 3, kr1, vr1);
+    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch above the MFMAs (hipcc otherwise sinks the loads)
     compute(kt, 0);
-    __syncthreads();
+    lds_barrier();
     if (kt + 1 >= n_kt) break;
     // odd: stage 1 holds tile kt+1; slot 0 holds kt+2, slot 1 holds kt+3
-    if (kt + 2 < n_kt) store_tile(0, kr0, vr0);
+    if (kt + 2 < n_kt) store_tile(0, kt + 2, kr0, vr0);
     load_tile(kt + 4, kr0, vr0);
+    __builtin_amdgcn_sched_barrier(0);
     compute(kt + 1, 1);
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- epilogue: lane holds O[tq][dt*16 + 4*fq + r]

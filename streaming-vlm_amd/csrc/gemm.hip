@@ -73,21 +73,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   for (int p = 0; p < W_PASSES; ++p) w_ptr[p] = W + (size_t)min(n0 + p * 32 + lrow, N - 1) * ldw + lchunk * 8;
 
   u32x4_t ra0[A_PASSES], rw0[W_PASSES], ra1[A_PASSES], rw1[W_PASSES];
-  auto load_tile = [&](int kt, u32x4_t (&ra)[A_PASSES], u32x4_t (&rw)[W_PASSES]) {
-    const int k0 = k_begin + kt * GEMM_BK;
-    const bool kin = kt < nk && (k0 + lchunk * 8) < k_end;
+  bool kin0 = true, kin1 = true;       // per ring slot: does this thread's chunk lie inside [k_begin, k_end)?
+  auto load_tile = [&](int kt, u32x4_t (&ra)[A_PASSES], u32x4_t (&rw)[W_PASSES], bool& kin_slot) {
+    // UNCONDITIONAL loads from clamped addresses (a predicated load becomes a branch, and hipcc then drains the whole
+    // ring with vmcnt(0) instead of a counted wait); out-of-range chunks are zeroed by a select afterwards
+    const int kt_c = min(kt, nk - 1);
+    const int k0 = k_begin + kt_c * GEMM_BK;
+    const bool kin = kt < nk && (k0 + lchunk * 8) < k_end;     // tiles past the end are stored as zeros
+    const int koff = (k0 + lchunk * 8) < k_end ? k0 : k_end - 8 - lchunk * 8;
+    kin_slot = kin;                    // the zeroing select happens at STORE time so the loads stay in flight
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) ra[p] = kin ? *reinterpret_cast<const u32x4_t*>(a_ptr[p] + k0) : u32x4_t{0, 0, 0, 0};
+    for (int p = 0; p < A_PASSES; ++p) ra[p] = *reinterpret_cast<const u32x4_t*>(a_ptr[p] + koff);
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) rw[p] = kin ? *reinterpret_cast<const u32x4_t*>(w_ptr[p] + k0) : u32x4_t{0, 0, 0, 0};
+    for (int p = 0; p < W_PASSES; ++p) rw[p] = *reinterpret_cast<const u32x4_t*>(w_ptr[p] + koff);
   };
-  auto store_tile = [&](int buf, const u32x4_t (&ra)[A_PASSES], const u32x4_t (&rw)[W_PASSES]) {
+  auto store_tile = [&](int buf, const u32x4_t (&ra)[A_PASSES], const u32x4_t (&rw)[W_PASSES], bool kin) {
     bf16_t* As = smem + buf * STAGE;
     bf16_t* Ws = As + BM * GEMM_LD;
+    const u32x4_t z = u32x4_t{0, 0, 0, 0};
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<u32x4_t*>(As + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = ra[p];
+    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<u32x4_t*>(As + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = kin ? ra[p] : z;
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<u32x4_t*>(Ws + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = rw[p];
+    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<u32x4_t*>(Ws + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = kin ? rw[p] : z;
   };
 
   f32x4_t acc[TM][4];
@@ -118,24 +125,26 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   };
 
   // prologue: tile 0 -> LDS[0]; tiles 1, 2 in flight in the register ring
-  load_tile(0, ra0, rw0);
-  load_tile(1, ra1, rw1);
-  store_tile(0, ra0, rw0);
-  load_tile(2, ra0, rw0);
+  load_tile(0, ra0, rw0, kin0);
+  load_tile(1, ra1, rw1, kin1);
+  store_tile(0, ra0, rw0, kin0);
+  load_tile(2, ra0, rw0, kin0);
   __syncthreads();
-  // steady state, unrolled by two so that the ring slots are named registers
+  // steady state, unrolled by two so that the ring slots are named registers.  The body is branch-free: tiles past
+  // the end of the K range are zeros (select at store time), so an odd tile count just computes one null tile.
   for (int kt = 0; kt < nk; kt += 2) {
     // even step: LDS[0] holds tile kt; ring slot 1 holds tile kt+1, slot 0 holds tile kt+2
-    if (kt + 1 < nk) store_tile(1, ra1, rw1);
-    load_tile(kt + 3, ra1, rw1);
+    store_tile(1, ra1, rw1, kin1);
+    load_tile(kt + 3, ra1, rw1, kin1);
+    __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE the MFMAs: hipcc otherwise sinks the loads below them
     compute(0);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
+    lds_barrier();
     // odd step: LDS[1] holds tile kt+1; slot 0 holds tile kt+2, slot 1 holds tile kt+3
-    if (kt + 2 < nk) store_tile(0, ra0, rw0);
-    load_tile(kt + 4, ra0, rw0);
+    store_tile(0, ra0, rw0, kin0);
+    load_tile(kt + 4, ra0, rw0, kin0);
+    __builtin_amdgcn_sched_barrier(0);
     compute(1);
-    __syncthreads();
+    lds_barrier();
   }
 
   // epilogue: lane holds m = fr (column of D), n = 4*fq + r (rows of D)
