@@ -52,6 +52,27 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Cross-row reductions without the LDS crossbar: __shfl_xor lowers to ds_bpermute (~100 cycles of latency on the
+// critical path of a one-wave-per-SIMD attention loop); v_permlane16/32_swap are plain VALU.
+// permlaneNN_swap(x, x) returns {x with odd/upper part replaced by the even/lower part, x with even/lower part
+// replaced by the odd/upper part}, so op(r[0], r[1]) is the xor-16 / xor-32 butterfly step for max and sum.
+__device__ __forceinline__ float xor16_max(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT.  __syncthreads() carries a release fence
 // for which hipcc emits s_waitcnt vmcnt(0) (gfx950 counts loads and stores on one counter), draining a software
 // prefetch ring at every K-tile; here only this wave's LDS traffic is waited for.  The asm memory clobber keeps

@@ -147,8 +147,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
         sc[sub * 4 + r] = s_;
         mx = fmaxf(mx, s_);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = xor32_max(xor16_max(mx));
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __expf(m_run - m_new);
     float p[8], rs = 0.f;
@@ -157,8 +156,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       p[i] = sc[i] > -1e29f ? __expf(sc[i] - m_new) : 0.f;
       rs += p[i];
     }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
+    rs = xor32_sum(xor16_sum(rs));
     l_run = l_run * alpha + rs;
     m_run = m_new;
     u32x4_t pk = pack8(p);
