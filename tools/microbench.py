@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Launch one kernel of the path repeatedly on BASELINE shapes (for rocprofv3 --pmc / --kernel-trace runs).
+    python tools/microbench.py vit_attn|prefill_attn|gemm_fc2|gemm_qkv|decode_attn|gemv_down [reps]"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from streaming_vlm_amd.ops import HipOps  # noqa: E402
+
+which = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+o = HipOps()
+dev = "cuda"
+bf = torch.bfloat16
+r = lambda *s: torch.randn(*s, device=dev).to(bf)
+if which == "vit_attn":
+    qkv, out = r(1024, 3840), torch.empty(1024, 1280, dtype=bf, device=dev)
+    fn = lambda: o.vit_attn(qkv, 1, 1024, 16, 80, 80 ** -0.5, out=out)
+elif which == "prefill_attn":
+    Hq, Hkv, T, L = 12, 2, 275, 2400
+    pool = r(1, 2, Hkv, 2560, 128)
+    slot = torch.arange(2560, dtype=torch.int32, device=dev)
+    rope = r(2560, 128)
+    q, out = r(T, Hq * 128), torch.empty(T, Hq * 128, dtype=bf, device=dev)
+    fn = lambda: o.prefill_attn(q, pool, 0, slot, rope, out, T, L, Hq, 128 ** -0.5)
+elif which.startswith("gemm"):
+    M, N, K = {"gemm_fc2": (1024, 1280, 5120), "gemm_qkv": (1024, 3840, 1280), "gemm_fc1": (1024, 5120, 1280),
+               "gemm_gu": (275, 17920, 1536), "gemm_down": (275, 1536, 8960)}[which]
+    A, W, C = r(M, K), r(N, K), torch.empty(M, N, dtype=bf, device=dev)
+    fn = lambda: o.gemm(A, W, out=C)
+elif which == "decode_attn":
+    Hq, Hkv, L = 12, 2, 2350
+    pool = r(1, 2, Hkv, 2560, 128)
+    slot = torch.arange(2560, dtype=torch.int32, device=dev)
+    rope = r(2560, 128)
+    q, out = r(Hq * 128), torch.empty(Hq * 128, dtype=bf, device=dev)
+    ws = o.decode_attn_ws(Hq, 2560, 32, dev)
+    fn = lambda: o.decode_attn(q, pool, 0, slot, rope, out, ws, Hq, 2560, 32, 128 ** -0.5, length=L)
+elif which == "gemv_down":
+    x, W, y = r(8960), r(1536, 8960), torch.zeros(1536, dtype=bf, device=dev)
+    fn = lambda: o.gemv(x, W, residual=y, out=y)
+else:
+    raise SystemExit(f"unknown kernel {which}")
+for _ in range(reps):
+    fn()
+torch.cuda.synchronize()
+print("done", which, reps)
