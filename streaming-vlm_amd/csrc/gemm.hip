@@ -19,7 +19,8 @@
 
 #define GEMM_BN 128
 #define GEMM_BK 64
-#define GEMM_LD 72  // padded LDS row stride in bf16 (144 B)
+#define GEMM_LD 64  // LDS row = 128 B, 16-B chunk c of row r lives at chunk position c ^ (r & 7): conflict-free for the
+                    // ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) and for the 8-lane ds_write_b128 groups
 
 extern __shared__ __attribute__((aligned(16))) unsigned char gemm_dyn_smem[];
 
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     bf16_t* Ws = As + BM * GEMM_LD;
     const u32x4_t z = u32x4_t{0, 0, 0, 0};
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<u32x4_t*>(As + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = kin ? ra[p] : z;
+    for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<u32x4_t*>(As + (p * 32 + lrow) * GEMM_LD + ((lchunk ^ (lrow & 7)) * 8)) = kin ? ra[p] : z;
 #pragma unroll
-    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<u32x4_t*>(Ws + (p * 32 + lrow) * GEMM_LD + lchunk * 8) = kin ? rw[p] : z;
+    for (int p = 0; p < W_PASSES; ++p) *reinterpret_cast<u32x4_t*>(Ws + (p * 32 + lrow) * GEMM_LD + ((lchunk ^ (lrow & 7)) * 8)) = kin ? rw[p] : z;
   };
 
   f32x4_t acc[TM][4];
@@ -112,10 +113,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
       bf16x8_t af[TM], wf[4];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * 16 * TM + i * 16 + fr) * GEMM_LD + ks * 32 + fq * 8);
+        af[i] = *reinterpret_cast<const bf16x8_t*>(As + (wm * 16 * TM + i * 16 + fr) * GEMM_LD + (((ks * 4 + fq) ^ (fr & 7)) * 8));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + (wn * 64 + j * 16 + fr) * GEMM_LD + ks * 32 + fq * 8);
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(Ws + (wn * 64 + j * 16 + fr) * GEMM_LD + (((ks * 4 + fq) ^ (fr & 7)) * 8));
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -222,22 +223,31 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
   if (M == 0) return SVLM_OK;
   hipStream_t st = (hipStream_t)stream;
   const int gn = (N + GEMM_BN - 1) / GEMM_BN;
-  // 64-row tiles whenever 128-row tiles would leave CUs idle (or waste most of a ragged last tile)
-  const long long tiles128 = (long long)((M + 127) / 128) * gn;
-  const int waste128 = (M + 127) / 128 * 128 - M, waste64 = (M + 63) / 64 * 64 - M;
-  const bool small = (M <= 64) || tiles128 < 256 || (waste128 - waste64 >= 64);
-  const int bm = small ? 64 : 128;
-  const int gm = (M + bm - 1) / bm;
-  const long long tiles = (long long)gm * gn;
-  // split K until ~2 workgroups per CU, keeping >= 512 of K per split
-  int splits = 1;
-  if (ws != nullptr && tiles < 384 && K >= 1024) {
-    splits = (int)((512 + tiles - 1) / tiles);
-    if (splits > K / 512) splits = K / 512;
-    if (splits > 16) splits = 16;
-    while (splits > 1 && (long long)splits * M * N * 4 > ws_bytes) --splits;
-    if (splits < 1) splits = 1;
+  // ---- tile height and K-split from a small cost model.  The path's GEMMs are one or two "rounds" of resident
+  // workgroups, so quantisation decides: cost = rounds x K-steps per workgroup x step cost (+ slab traffic).
+  // Resident workgroups per CU: LDS 2 x (BM+128) x 128 B -> 48 KB (BM=64): 3, 64 KB (BM=128): 2.
+  int best_bm = 64, best_splits = 1;
+  double best_cost = 1e30;
+  for (int bm_c = 64; bm_c <= 128; bm_c += 64) {
+    if (bm_c == 128 && M <= 64) continue;
+    const long long tiles_c = (long long)((M + bm_c - 1) / bm_c) * gn;
+    const long long cap = 256LL * (bm_c == 64 ? 3 : 2);
+    const int max_s = ws != nullptr ? (K >= 1024 ? (K / 512 < 16 ? K / 512 : 16) : 1) : 1;
+    for (int sp = 1; sp <= max_s; ++sp) {
+      if (sp > 1 && (long long)sp * M * N * 4 > ws_bytes) break;
+      const long long wgs = tiles_c * sp;
+      const double rounds = (double)((wgs + cap - 1) / cap);
+      const double ksteps = (double)((K + sp - 1) / sp + GEMM_BK - 1) / GEMM_BK + 3.0;           // + prologue/epilogue
+      const double step_us = bm_c == 64 ? 0.9 : 1.5;                                              // measured per K-step
+      const double slab_us = sp > 1 ? 2.0 * sp * M * N * 4.0 / 3e12 * 1e6 + 5.0 : 0.0;            // slab write+read + reduce launch
+      const double cost = rounds * ksteps * step_us + slab_us;
+      if (cost < best_cost) { best_cost = cost; best_bm = bm_c; best_splits = sp; }
+    }
   }
+  const bool small = best_bm == 64;
+  const int bm = best_bm;
+  const int gm = (M + bm - 1) / bm;
+  int splits = best_splits;
   int kps = K;
   if (splits > 1) {
     kps = ((K + splits - 1) / splits + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
