@@ -56,6 +56,10 @@ int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* b
 int svlm_gemv_bf16(const void* x, const void* W, int ldw, const void* bias, const void* residual, void* y, float* y_f32,
                    int N, int K, int act, void* stream);
 
+/* Warm the 256 MiB Infinity Cache with [ptr, ptr+bytes) (16-B aligned) using n_wgs workgroups; a pure performance
+ * hint for the weight stream of the next decode layer, launched on a side stream.  No reference counterpart. */
+int svlm_prefetch(const void* ptr, long long bytes, int n_wgs, void* stream);
+
 /* replaces: Qwen2RMSNorm (qwen2/language_forward.py:183,200,315). */
 int svlm_rmsnorm(const void* x, const void* w, void* y, int rows, int cols, float eps, void* stream);
 /* replaces: nn.LayerNorm of the ViT blocks and merger (qwen2/vision_forward.py:43-49,80). */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "svlm_device_cus": (_i, []),
     "svlm_gemm_bf16": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _ll, _p]),
     "svlm_gemv_bf16": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "svlm_prefetch": (_i, [_p, _ll, _i, _p]),
     "svlm_rmsnorm": (_i, [_p, _p, _p, _i, _i, _f, _p]),
     "svlm_layernorm": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "svlm_add": (_i, [_p, _p, _p, _ll, _p]),

@@ -150,6 +150,27 @@ __global__ void vit_rope_kernel(bf16_t* __restrict__ qkv, const float* __restric
   }
 }
 
+// ---------------------------------------------------------------- Infinity-Cache warm-up
+// Streams a byte range through plain 16-B loads and throws the data away: the lines stay in the 256 MiB
+// Infinity Cache.  Launched on a side stream for the NEXT layer's weights while the current layer's
+// latency-bound kernels (QKV, attention, o_proj) leave HBM idle; purely a performance hint (no result,
+// nothing depends on it).
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4_t* __restrict__ p, long n16) {
+  const long stride = (long)gridDim.x * 256;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    u32x4_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(v[u]));
+  }
+  for (; i < n16; i += stride) {
+    u32x4_t v = p[i];
+    asm volatile("" ::"v"(v));
+  }
+}
+
 // ================================================================ host launchers
 static inline int grid_for(size_t n, int block) {
   size_t g = (n + block - 1) / block;
@@ -198,4 +219,11 @@ extern "C" int svlm_vit_rope(void* qkv, const float* cosT, const float* sinT, in
   if (N == 0) return SVLM_OK;
   vit_rope_kernel<<<grid_for((size_t)N * 2 * H * (d / 2), 256), 256, 0, (hipStream_t)stream>>>((bf16_t*)qkv, cosT, sinT, N, H, d);
   return svlm_check_launch("svlm_vit_rope");
+}
+
+extern "C" int svlm_prefetch(const void* ptr, long long bytes, int n_wgs, void* stream) {
+  SVLM_CHECK_ARG(ptr != nullptr && bytes >= 0 && n_wgs > 0 && ((uintptr_t)ptr & 15) == 0, "svlm_prefetch: bad range");
+  if (bytes < 16) return SVLM_OK;
+  prefetch_kernel<<<n_wgs, 256, 0, (hipStream_t)stream>>>((const u32x4_t*)ptr, bytes / 16);
+  return svlm_check_launch("svlm_prefetch");
 }

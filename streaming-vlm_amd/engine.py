@@ -59,6 +59,9 @@ class SvlmEngine:
             decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / target / 16))))
         self.decode_chunk = int(decode_chunk)
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
+        # weight prefetch of layer l+1 on a side stream while layer l computes (Infinity-Cache warm-up; speed only)
+        self.prefetch = os.environ.get("SVLM_PREFETCH", "1") == "1" and self.device.type == "cuda"
+        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
         dev = self.device
         H, V = tc.hidden_size, tc.vocab_size
         self.qd, self.kd = tc.num_heads * tc.head_dim, tc.num_kv_heads * tc.head_dim
@@ -185,7 +188,12 @@ class SvlmEngine:
         kv_len = self.state[0:1]
         scale = 1.0 / math.sqrt(tc.head_dim)
         o.gather_rows(w.embed, None, self.tok_buf, self.d_x.view(1, H), idx_off=self.state[1:2])
+        main = torch.cuda.current_stream() if self.prefetch else None
         for li, lw in enumerate(w.layers):
+            if self.prefetch and li + 1 < len(w.layers):
+                self._side.wait_stream(main)                       # fork: starts when layer li starts
+                with torch.cuda.stream(self._side):
+                    o.prefetch(w.layers[li + 1]["flat"])
             o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
                       len_dev=kv_len)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
@@ -193,6 +201,8 @@ class SvlmEngine:
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
             o.dec_gate_up(self.d_x, lw["ln2"], tc.rms_eps, lw["gu_w"], self.d_h)
             o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)
+        if self.prefetch:
+            main.wait_stream(self._side)                           # join (required to close a graph capture)
         o.dec_lm_head(self.d_x, w.final_norm, tc.rms_eps, w.lm_head, self.logits, self.seen if self._penalty != 1.0 else None,
                       self._penalty, self._suppress, self.d_sws)
 

@@ -96,6 +96,11 @@ class HipOps:
                                       N, K, act, _stream()), "svlm_gemv_bf16")
         return out if out is not None else out_f32
 
+    def prefetch(self, t, n_wgs=256):
+        """Infinity-Cache warm-up of a contiguous tensor on the CURRENT stream (callers put it on a side stream)."""
+        assert t.is_cuda and t.is_contiguous()
+        check(self.lib.svlm_prefetch(_ptr(t), t.numel() * t.element_size(), int(n_wgs), _stream()), "svlm_prefetch")
+
     def rmsnorm(self, x, w, eps, out=None):
         _req(x, BF16, "rmsnorm.x"); _req(w, BF16, "rmsnorm.w", 1)
         cols = x.shape[-1]

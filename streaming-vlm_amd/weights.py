@@ -101,13 +101,22 @@ class EngineWeights:
             qkv_w = torch.cat([sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0)
             qkv_b = torch.cat([sd[p + "self_attn.q_proj.bias"], sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0)
             gu_w = torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0)
-            self.layers.append(dict(ln1=dev(sd[p + "input_layernorm.weight"]), ln2=dev(sd[p + "post_attention_layernorm.weight"]),
-                                    qkv_w=dev(qkv_w), qkv_b=dev(qkv_b), o_w=dev(sd[p + "self_attn.o_proj.weight"]),
-                                    gu_w=dev(gu_w), down_w=dev(sd[p + "mlp.down_proj.weight"])))
+            # the four matrices of a layer live back to back in ONE buffer (streamed in this order by a decode step),
+            # so the next layer can be pulled into the Infinity Cache with a single range prefetch
+            mats = [("qkv_w", qkv_w), ("o_w", sd[p + "self_attn.o_proj.weight"]), ("gu_w", gu_w), ("down_w", sd[p + "mlp.down_proj.weight"])]
+            flat = torch.empty(sum(m.numel() for _, m in mats), dtype=torch.bfloat16, device=device)
+            layer = dict(ln1=dev(sd[p + "input_layernorm.weight"]), ln2=dev(sd[p + "post_attention_layernorm.weight"]), qkv_b=dev(qkv_b), flat=flat)
+            off = 0
+            for name, m in mats:
+                view = flat[off:off + m.numel()].view(m.shape)
+                view.copy_(m)
+                layer[name] = view
+                off += m.numel()
+            self.layers.append(layer)
 
     def nbytes_llm_decode(self) -> int:
         """Weight bytes one decode step streams (layers + final norm + lm_head)."""
         n = self.lm_head.numel() + self.final_norm.numel()
         for l in self.layers:
-            n += sum(t.numel() for t in l.values())
+            n += sum(t.numel() for k, t in l.items() if k != "flat")
         return n * 2

@@ -48,6 +48,9 @@ class RefOps:
             out_f32.copy_(y.float())
         return out if out is not None else out_f32
 
+    def prefetch(self, t, n_wgs=256):
+        pass
+
     def rmsnorm(self, x, w, eps, out=None):
         y = om.rms_norm(x, w, eps)
         if out is None:
