@@ -59,8 +59,10 @@ class SvlmEngine:
             decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / target / 16))))
         self.decode_chunk = int(decode_chunk)
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
-        # weight prefetch of layer l+1 on a side stream while layer l computes (Infinity-Cache warm-up; speed only)
-        self.prefetch = os.environ.get("SVLM_PREFETCH", "1") == "1" and self.device.type == "cuda"
+        # EXPERIMENT, off by default: Infinity-Cache prefetch of layer l+1's weights on a side stream while layer l computes.
+        # Measured on MI355X (2B, round 1): 52.7 ms/chunk with it vs 38.2 without -- the 27 fork/joins per step and the
+        # contention with the foreground GEMVs cost more than the warm lines save.  Kept for the persistent-kernel work.
+        self.prefetch = os.environ.get("SVLM_PREFETCH", "0") == "1" and self.device.type == "cuda"
         self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
         dev = self.device
         H, V = tc.hidden_size, tc.vocab_size

@@ -39,6 +39,12 @@ elif which == "decode_attn":
     q, out = r(Hq * 128), torch.empty(Hq * 128, dtype=bf, device=dev)
     ws = o.decode_attn_ws(Hq, 2560, 32, dev)
     fn = lambda: o.decode_attn(q, pool, 0, slot, rope, out, ws, Hq, 2560, 32, 128 ** -0.5, length=L)
+elif which == "dec_gate_up":
+    # 28 DIFFERENT weight matrices (1.5 GB > Infinity Cache), like the 28 layers of a decode step
+    H, I = 1536, 8960
+    Ws = [r(2 * I, H) for _ in range(28)]
+    x, lnw, h = r(H), r(H), torch.empty(I, dtype=bf, device=dev)
+    fn = lambda: [o.dec_gate_up(x, lnw, 1e-6, W, h) for W in Ws]
 elif which == "gemv_down":
     x, W, y = r(8960), r(1536, 8960), torch.zeros(1536, dtype=bf, device=dev)
     fn = lambda: o.gemv(x, W, residual=y, out=y)
