@@ -16,6 +16,7 @@
 // tile grid cannot cover the 256 CUs the K range is split over grid.z, fp32 partial slabs go to a
 // caller-provided workspace and a second kernel sums them and applies the epilogue.
 #include "common.h"
+#include <stdlib.h>
 
 #define GEMM_BN 128
 #define GEMM_BK 64
@@ -180,6 +181,150 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (K % 64 == 0): tiles go global -> LDS with `global_load_lds_dwordx4`, never through VGPRs, so
+// the ds_write pass (≈80 B/clk/CU, slower than the MFMAs it feeds) disappears and three stages fit a deeper
+// prefetch: tile t+2 is in flight while tile t is computed.  The LDS image of a wave-instruction is lane-linear
+// (lane i -> base + 16 i), so the XOR swizzle is applied to the per-lane SOURCE address (chunk c = p ^ (row & 7)
+// lands at position p) and again on the fragment reads.  Waits are counted by hand (vmcnt(NPT) leaves exactly the
+// newest tile in flight) and the barrier is raw: __syncthreads() would drain the DMA queue.
+#define GLDS(gp, lp) \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
+
+template <int TM>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict__ A, int lda,
+                                                        const bf16_t* __restrict__ W, int ldw,
+                                                        const bf16_t* __restrict__ bias,
+                                                        const bf16_t* residual, int ldr,
+                                                        bf16_t* C, int ldc, float* __restrict__ partial,
+                                                        int M, int N, int K, int k_per_split, int act, int gm, int gn, int splits) {
+  constexpr int BM = 32 * TM;
+  constexpr int A_INST = BM / 32;               // 1-KiB DMA pieces (8 rows x 128 B) per wave per tile: A
+  constexpr int W_INST = GEMM_BN / 32;          // ... and W
+  constexpr int NPT = A_INST + W_INST;          // DMA instructions per wave per tile
+  constexpr int STAGE_B = (BM + GEMM_BN) * 128; // bytes per stage
+  unsigned char* smem = gemm_dyn_smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = blockIdx.x;
+  int tm, tn, split;
+  if (splits > 1) {
+    split = bid % splits;
+    const int t = bid / splits;
+    tn = t % gn;
+    tm = t / gn;
+  } else {
+    split = 0;
+    const int npx = (gn + 7) / 8;
+    const int local = bid / 8;
+    tn = (bid % 8) * npx + local / gm;
+    tm = local % gm;
+    if (tn >= gn) return;
+  }
+  const int m0 = tm * BM, n0 = tn * GEMM_BN;
+  const int k_begin = split * k_per_split;
+  const int k_end = min(K, k_begin + k_per_split);
+  const int nk = (k_end - k_begin) / GEMM_BK;    // K % 64 == 0 and k_per_split % 64 == 0
+
+  // per-lane source pointers of this wave's DMA pieces (row = piece*8 + lane/8, position p = lane%8 holds chunk p^(row&7))
+  const int rsub = lane >> 3, ppos = lane & 7;
+  const bf16_t* a_src[A_INST];
+  const bf16_t* w_src[W_INST];
+#pragma unroll
+  for (int i = 0; i < A_INST; ++i) {
+    const int row = (wave * A_INST + i) * 8 + rsub;
+    a_src[i] = A + (size_t)min(m0 + row, M - 1) * lda + k_begin + ((ppos ^ (row & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < W_INST; ++i) {
+    const int row = (wave * W_INST + i) * 8 + rsub;
+    w_src[i] = W + (size_t)min(n0 + row, N - 1) * ldw + k_begin + ((ppos ^ (row & 7)) * 8);
+  }
+  auto issue = [&](int kt, int stage) {
+    unsigned char* sa = smem + stage * STAGE_B;
+    unsigned char* sw = sa + BM * 128;
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) GLDS(a_src[i] + kt * GEMM_BK, sa + (wave * A_INST + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < W_INST; ++i) GLDS(w_src[i] + kt * GEMM_BK, sw + (wave * W_INST + i) * 1024);
+  };
+
+  f32x4_t acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int stage) {
+    const unsigned char* sa = smem + stage * STAGE_B;
+    const unsigned char* sw = sa + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[TM], wf[4];
+      const int pos = ((ks * 4 + fq) ^ (fr & 7)) * 16;      // rows of a fragment differ by multiples of 16 -> row&7 == fr&7
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(sa + (wm * 16 * TM + i * 16 + fr) * 128 + pos);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(sw + (wn * 64 + j * 16 + fr) * 128 + pos);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // prologue: two tiles in flight
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed when at most the NEWER tile's NPT pieces are outstanding; then everyone passed compute(kt-1),
+    // whose stage ((kt+2) % 3) may be refilled
+    if (kt + 1 < nk) {
+      if constexpr (NPT == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
+    compute(kt % 3);
+  }
+
+  // epilogue: lane holds m = fr (column of D), n = 4*fq + r (rows of D)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * 16 * TM + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+      if (n >= N) continue;
+      if (partial) {
+        *reinterpret_cast<f32x4_t*>(partial + ((size_t)split * M + m) * N + n) = acc[i][j];
+        continue;
+      }
+      float y[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (bias) {
+        u32x2_t bv = *reinterpret_cast<const u32x2_t*>(bias + n);
+        y[0] += lo_bf(bv[0]); y[1] += hi_bf(bv[0]); y[2] += lo_bf(bv[1]); y[3] += hi_bf(bv[1]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = apply_act(rbf(y[r]), act);
+      if (residual) {
+        u32x2_t rv = *reinterpret_cast<const u32x2_t*>(residual + (size_t)m * ldr + n);
+        y[0] = y[0] + lo_bf(rv[0]); y[1] = y[1] + hi_bf(rv[0]); y[2] = y[2] + lo_bf(rv[1]); y[3] = y[3] + hi_bf(rv[1]);
+      }
+      u32x2_t o;
+      o[0] = pack2(y[0], y[1]);
+      o[1] = pack2(y[2], y[3]);
+      *reinterpret_cast<u32x2_t*>(C + (size_t)m * ldc + n) = o;
+    }
+  }
+}
+
 // C = epi(sum_z partial[z]) -- one thread per 4 consecutive n
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
                                                                  const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
@@ -268,7 +413,27 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
     }
     attr_done = true;
   }
-  if (small) {
+  const bool dma = (K % GEMM_BK == 0) && getenv("SVLM_GEMM_NO_DMA") == nullptr;
+  if (dma) {
+    constexpr int DLDS2 = 3 * (64 + GEMM_BN) * 128, DLDS4 = 3 * (128 + GEMM_BN) * 128;
+    static bool dma_attr_done = false;
+    if (!dma_attr_done) {
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS2);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS4);
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", DLDS4, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        return SVLM_ELAUNCH;
+      }
+      dma_attr_done = true;
+    }
+    if (small) {
+      gemm_glds_kernel<2><<<grid, 256, DLDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                               (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+    } else {
+      gemm_glds_kernel<4><<<grid, 256, DLDS4, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                               (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+    }
+  } else if (small) {
     gemm_bf16_kernel<2><<<grid, 256, LDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                              (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
   } else {
