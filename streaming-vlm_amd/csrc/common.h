@@ -41,15 +41,39 @@ __device__ __forceinline__ u32x4_t pack8(const float (&f)[8]) {
   return v;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide reductions on the VALU only: DPP quad_perm / row mirrors inside each 16-lane row, then
+// v_permlane16/32_swap across rows (a __shfl_xor butterfly is six ds_bpermute round trips through the LDS crossbar).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum(float v) {      // all 16 lanes of a row end up with the row total
+  v += dpp_f<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);    // row_half_mirror
+  v += dpp_f<0x140>(v);    // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum(v);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row_max(v);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // Cross-row reductions without the LDS crossbar: __shfl_xor lowers to ds_bpermute (~100 cycles of latency on the

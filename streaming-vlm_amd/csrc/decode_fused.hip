@@ -52,16 +52,47 @@ __device__ __forceinline__ void stage_x(const bf16_t* __restrict__ x, const bf16
   __syncthreads();
 }
 
+// The first PRE K-steps (512 elements each) of a wave's weight rows are requested BEFORE the activation row is
+// normalised and staged: weights do not depend on x, so the HBM latency of the stream's head overlaps the norm.
+#define DEC_PRE 2
+template <int NR>
+struct WPre {
+  u32x4_t w[DEC_PRE][NR];
+};
+template <int NR>
+__device__ __forceinline__ void preload_w(const bf16_t* const (&wr)[NR], int K, WPre<NR>& pre) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int it = 0; it < DEC_PRE; ++it) {
+    const int c = min(it * 512 + lane * 8, K - 8);          // clamped (valid) address; unused when past K
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pre.w[it][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
+  }
+}
+
 // acc[r] = W[row[r]] . xs   for NR rows of one wave
 template <int NR>
-__device__ __forceinline__ void wave_dots(const bf16_t* const (&wr)[NR], const bf16_t* xs, int K, float (&acc)[NR]) {
+__device__ __forceinline__ void wave_dots(const bf16_t* const (&wr)[NR], const bf16_t* xs, int K, float (&acc)[NR], const WPre<NR>& pre) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-  const int nfull = K / 512;
-#pragma unroll 2
-  for (int it = 0; it < nfull; ++it) {
+#pragma unroll
+  for (int it = 0; it < DEC_PRE; ++it) {
     const int c = it * 512 + lane * 8;
+    if (c < K) {
+      float xf[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(xs + c), xf);
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        float wf[8];
+        unpack8(pre.w[it][r], wf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
+      }
+    }
+  }
+#pragma unroll 2
+  for (int c = DEC_PRE * 512 + lane * 8; c < K; c += 512) {
     u32x4_t wv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
@@ -71,18 +102,6 @@ __device__ __forceinline__ void wave_dots(const bf16_t* const (&wr)[NR], const b
     for (int r = 0; r < NR; ++r) {
       float wf[8];
       unpack8(wv[r], wf);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
-    }
-  }
-  const int c = nfull * 512 + lane * 8;
-  if (c < K) {
-    float xf[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(xs + c), xf);
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      float wf[8];
-      unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c)), wf);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
     }
@@ -100,22 +119,28 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__
                                                       const int* __restrict__ len_dev, int len_host, int N, int K, int qd, int kd,
                                                       int D, int n_slots) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
-  stage_x<true>(x, ln_w, eps, K, xs);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + wave) * ROWS;
-  if (n0 >= N) return;
   const bf16_t* wr[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, N - 1) * ldw;
+  // everything that does not depend on x is requested first: head of the weight stream, the slot, the bias
+  WPre<ROWS> pre;
+  preload_w<ROWS>(wr, K, pre);
+  const int slot = slot_of[len_dev ? *len_dev : len_host];
+  float bpre[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) bpre[r] = bf2f(bias[min(n0 + r, N - 1)]);
+  stage_x<true>(x, ln_w, eps, K, xs);
+  if (n0 >= N) return;
   float acc[ROWS];
-  wave_dots<ROWS>(wr, xs, K, acc);
+  wave_dots<ROWS>(wr, xs, K, acc, pre);
   if (lane == 0) {
-    const int slot = slot_of[len_dev ? *len_dev : len_host];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;
       if (n >= N) break;
-      const bf16_t v = f2bf(acc[r] + bf2f(bias[n]));
+      const bf16_t v = f2bf(acc[r] + bpre[r]);
       if (n < qd) {
         q_out[n] = v;
       } else {
@@ -133,10 +158,8 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void dec_gate_up_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
                                                           const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ h, int I, int K) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
-  stage_x<true>(x, ln_w, eps, K, xs);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + wave) * ROWS;
-  if (n0 >= I) return;
   const bf16_t* wr[2 * ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -144,8 +167,12 @@ __global__ __launch_bounds__(256) void dec_gate_up_kernel(const bf16_t* __restri
     wr[r] = W + (size_t)n * ldw;               // gate row n
     wr[ROWS + r] = W + (size_t)(I + n) * ldw;  // up row n
   }
+  WPre<2 * ROWS> pre;
+  preload_w<2 * ROWS>(wr, K, pre);
+  stage_x<true>(x, ln_w, eps, K, xs);
+  if (n0 >= I) return;
   float acc[2 * ROWS];
-  wave_dots<2 * ROWS>(wr, xs, K, acc);
+  wave_dots<2 * ROWS>(wr, xs, K, acc, pre);
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -165,17 +192,19 @@ __global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restri
                                                           const int* __restrict__ suppress, int n_suppress,
                                                           float* __restrict__ part_val, int* __restrict__ part_idx, int V, int K) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
-  stage_x<true>(x, ln_w, eps, K, xs);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + wave) * ROWS;
+  const bf16_t* wr[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, V - 1) * ldw;
+  WPre<ROWS> pre;
+  preload_w<ROWS>(wr, K, pre);
+  stage_x<true>(x, ln_w, eps, K, xs);
   float best = -INFINITY;
   int bi = 0x7fffffff;
   if (n0 < V) {
-    const bf16_t* wr[ROWS];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, V - 1) * ldw;
     float acc[ROWS];
-    wave_dots<ROWS>(wr, xs, K, acc);
+    wave_dots<ROWS>(wr, xs, K, acc, pre);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;

@@ -389,6 +389,11 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
       if (cost < best_cost) { best_cost = cost; best_bm = bm_c; best_splits = sp; }
     }
   }
+  if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
+    best_bm = atoi(force) == 128 && M > 64 ? 128 : 64;
+    if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
+    if ((long long)best_splits * M * N * 4 > ws_bytes || ws == nullptr || K < 1024) best_splits = 1;
+  }
   const bool small = best_bm == 64;
   const int bm = best_bm;
   const int gm = (M + bm - 1) / bm;

@@ -21,9 +21,18 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     n = n < N ? n : N - 1;
     wr[r] = W + (size_t)n * ldw;
   }
-  float acc[ROWS];
+  float acc[ROWS], epi[ROWS];
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  for (int r = 0; r < ROWS; ++r) {
+    acc[r] = 0.f;
+    // residual / bias are requested up front so that their latency hides under the weight stream
+    const int n = min(n0 + r, N - 1);
+    epi[r] = (residual ? bf2f(residual[n]) : 0.f);
+    acc[r] = 0.f;
+  }
+  float bia[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) bia[r] = bias ? bf2f(bias[min(n0 + r, N - 1)]) : 0.f;
 
   const int nfull = K / 512;
 #pragma unroll 2
@@ -66,10 +75,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;
       if (n >= N) break;
-      float v = acc[r];
-      if (bias) v += bf2f(bias[n]);
+      float v = acc[r] + bia[r];
       v = apply_act(rbf(v), act);
-      if (residual) v = rbf(v + bf2f(residual[n]));
+      if (residual) v = rbf(v + epi[r]);
       if (y) y[n] = f2bf(v);
       if (y_f32) y_f32[n] = v;
     }
@@ -92,6 +100,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_ksplit_kernel(const bf16_t* __r
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  // epilogue operands requested up front (their latency hides under the weight stream)
+  float epi = 0.f, bia = 0.f;
+  if (threadIdx.x < ROWS) {
+    const int n = min(n0 + (int)threadIdx.x, N - 1);
+    if (residual) epi = bf2f(residual[n]);
+    if (bias) bia = bf2f(bias[n]);
+  }
 #pragma unroll 4
   for (int c = k_lo + lane * 8; c < k_hi; c += 512) {
     float xf[8];
@@ -114,10 +129,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_ksplit_kernel(const bf16_t* __r
   if (threadIdx.x < ROWS) {
     const int r = threadIdx.x, n = n0 + r;
     if (n < N) {
-      float v = part[0][r] + part[1][r] + part[2][r] + part[3][r];
-      if (bias) v += bf2f(bias[n]);
+      float v = part[0][r] + part[1][r] + part[2][r] + part[3][r] + bia;
       v = apply_act(rbf(v), act);
-      if (residual) v = rbf(v + bf2f(residual[n]));
+      if (residual) v = rbf(v + epi);
       if (y) y[n] = f2bf(v);
       if (y_f32) y_f32[n] = v;
     }

@@ -50,7 +50,13 @@ elif which == "gemv_down":
     fn = lambda: o.gemv(x, W, residual=y, out=y)
 else:
     raise SystemExit(f"unknown kernel {which}")
-for _ in range(reps):
+for _ in range(3):
     fn()
 torch.cuda.synchronize()
-print("done", which, reps)
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(reps):
+    fn()
+e.record()
+torch.cuda.synchronize()
+print("done", which, reps, "avg_us", round(1e3 * s.elapsed_time(e) / reps, 2), "env", {k: v for k, v in os.environ.items() if k.startswith("SVLM_")})
