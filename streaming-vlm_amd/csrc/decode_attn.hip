@@ -37,27 +37,28 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
     const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
     float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
-    int chunk, float scale) {
-  const int L = (len_dev ? *len_dev : 0) + len_add;
+    int chunk, float scale, int max_len) {
   const int start = blockIdx.x * chunk;
-  if (start >= L) return;
   const int kvh = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 4, s = lane & 15;
   const bool upper = s >= 8;
   const int fc = (s & 7) * 8;  // frequency chunk
-  const int end = min(start + chunk, L);
   const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D + s * 8;
   const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D + s * 8;
 
-  // ---- issue every load of this workgroup up front
+  // ---- issue every load of this workgroup up front.  The slot lookups do NOT wait for the length: rows past the
+  // end read stale-but-valid entries of slot_of (always < n_slots; the table is max_len long and max_len is a
+  // multiple of the chunk) and are masked later, so the length load and the slot loads overlap.
   int rows[DA_MAX_STEPS], slots[DA_MAX_STEPS];
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
-    const int r = start + it * 16 + wave * 4 + grp;
-    rows[it] = r < end ? r : end - 1;
+    rows[it] = min(start + it * 16 + wave * 4 + grp, max_len - 1);
     slots[it] = slot_of[rows[it]];
   }
+  const int L = (len_dev ? *len_dev : 0) + len_add;
+  if (start >= L) return;
+  const int end = min(start + chunk, L);
   u32x4_t qraw[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) qraw[g] = *reinterpret_cast<const u32x4_t*>(q + (size_t)(kvh * G + g) * DA_D + s * 8);
@@ -197,15 +198,33 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
   const int ns = (L + chunk - 1) / chunk;
   const int hq = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // first batch of this wave's partials is requested before anything depends on the global max
+  float m_[4], l_[4];
+  float2 v_[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i0 = min(wave + 4 * u, ns - 1);
+    const size_t p = (size_t)i0 * Hq + hq;
+    m_[u] = ws_m[p];
+    l_[u] = ws_l[p];
+    v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + 2 * lane);
+  }
   // global max over splits (every wave computes it redundantly: ns floats, L2-resident)
   float mx = -1e30f;
   for (int i = lane; i < ns; i += 64) mx = fmaxf(mx, ws_m[(size_t)i * Hq + hq]);
   mx = wave_max(mx);
   float l = 0.f, a0 = 0.f, a1 = 0.f;
-  int i = wave;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (wave + 4 * u < ns) {
+      const float e = __expf(m_[u] - mx);
+      l += l_[u] * e;
+      a0 += v_[u].x * e;
+      a1 += v_[u].y * e;
+    }
+  }
+  int i = wave + 16;
   for (; i + 12 < ns; i += 16) {
-    float m_[4], l_[4];
-    float2 v_[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const size_t p = (size_t)(i + 4 * u) * Hq + hq;
@@ -253,8 +272,8 @@ extern "C" long long svlm_decode_attn_ws_bytes(int Hq, int max_len, int chunk) {
 template <int G>
 static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* kp, const bf16_t* vp, const int* slot_of,
                          const bf16_t* cs, const int* len_dev, int len_add, float* ws_m, float* ws_l, float* ws_acc, int Hq, int Hkv,
-                         int n_slots, int chunk, float scale) {
-  decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale);
+                         int n_slots, int chunk, float scale, int max_len) {
+  decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
 }
 
 extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of,
@@ -273,7 +292,7 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
   hipStream_t st = (hipStream_t)stream;
   const bf16_t *qq = (const bf16_t*)q, *kp = (const bf16_t*)k_planes, *vp = (const bf16_t*)v_planes, *cs = (const bf16_t*)rope_cs;
 #define SVLM_DA_CASE(GG) \
-  case GG: launch_split<GG>(grid, st, qq, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale); break;
+  case GG: launch_split<GG>(grid, st, qq, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); break;
   switch (Hq / Hkv) {
     SVLM_DA_CASE(1) SVLM_DA_CASE(2) SVLM_DA_CASE(3) SVLM_DA_CASE(4) SVLM_DA_CASE(5) SVLM_DA_CASE(6) SVLM_DA_CASE(7) SVLM_DA_CASE(8)
   }
