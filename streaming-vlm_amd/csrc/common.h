@@ -16,17 +16,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
-// round-to-nearest-even, the rounding torch uses for fp32 -> bf16 (NaN inputs do not occur here)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
-
+// round-to-nearest-even, the rounding torch uses for fp32 -> bf16: the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// (one instruction per TWO values; the integer-arithmetic form costs five per value and these helpers sit on the
+// critical path of every RoPE-on-load and every epilogue)
+typedef __bf16 hw_bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  hw_bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float rbf(float f) { return __uint_as_float(((unsigned)f2bf(f)) << 16); }  // round through bf16
 __device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float hi_bf(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
 

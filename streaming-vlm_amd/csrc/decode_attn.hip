@@ -32,41 +32,60 @@ __device__ __forceinline__ void rope8(const float (&x)[8], const float (&xp)[8],
   }
 }
 
+// Split kernel on the matrix cores.  The G query heads of one kv head form the (padded-to-16) column block of two
+// small products per 16-key tile -- exactly the prefill kernel's scheme with "queries" = heads:
+//   S^T[key][head] = K_rot[key][:] . Q_rot[head][:]     (4 x v_mfma_f32_16x16x32_bf16, K rows from LDS)
+//   O^T[d][head]   = V^T[d][key] . P^T[key][head]       (8 x MFMA, V^T via ds_read_b64_tr_b16, half the k-slots used)
+// All 256 threads first stage the chunk: every thread rotates up to four 16-B pieces of un-rotated K (RoPE-on-load:
+// partner half through a DPP row rotate, cos/sin rows from the table) into LDS and copies V; then wave w owns the
+// 16-key tile w.  The VALU work per workgroup drops ~4x against one-dot-product-per-lane-group.
+typedef short v4s_da_t __attribute__((ext_vector_type(4)));
+#define DA_KLD 136   // K / Q LDS row stride (bf16): 272 B, conflict-free ds_read_b128 fragments
+#define DA_VLD 144   // V LDS row stride (bf16): 288 B, conflict-free ds_read_b64_tr_b16
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) { return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xF, 0xF, true); }
+
 template <int G>
 __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
     const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
     float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
     int chunk, float scale, int max_len) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2 + 512];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(lds);
+  bf16_t* Vs = Ks + 64 * DA_KLD;
+  bf16_t* Qs = Vs + 64 * DA_VLD;
+  float* Om = reinterpret_cast<float*>(lds);                     // [4][16][128] fp32, reuses Ks/Vs after the tiles are consumed
+  float* Mm = reinterpret_cast<float*>(lds + 64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2);   // [4][16]
+  float* Lm = Mm + 64;
+
   const int start = blockIdx.x * chunk;
   const int kvh = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane >> 4, s = lane & 15;
-  const bool upper = s >= 8;
-  const int fc = (s & 7) * 8;  // frequency chunk
-  const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D + s * 8;
-  const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D + s * 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int srow = tid >> 4, c = tid & 15;      // staging: 16 lanes per 256-B row
+  const bool upper = c >= 8;
+  const int fc = (c & 7) * 8;
+  const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D + c * 8;
+  const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D + c * 8;
 
-  // ---- issue every load of this workgroup up front.  The slot lookups do NOT wait for the length: rows past the
-  // end read stale-but-valid entries of slot_of (always < n_slots; the table is max_len long and max_len is a
-  // multiple of the chunk) and are masked later, so the length load and the slot loads overlap.
+  // ---- slot lookups do not wait for the length (stale entries are valid slots; masked later)
   int rows[DA_MAX_STEPS], slots[DA_MAX_STEPS];
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
-    rows[it] = min(start + it * 16 + wave * 4 + grp, max_len - 1);
+    rows[it] = min(start + it * 16 + srow, max_len - 1);
     slots[it] = slot_of[rows[it]];
   }
+  u32x4_t qraw = u32x4_t{0, 0, 0, 0};
+  if (srow < G) qraw = *reinterpret_cast<const u32x4_t*>(q + (size_t)(kvh * G + srow) * DA_D + c * 8);
   const int L = (len_dev ? *len_dev : 0) + len_add;
   if (start >= L) return;
-  const int end = min(start + chunk, L);
-  u32x4_t qraw[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) qraw[g] = *reinterpret_cast<const u32x4_t*>(q + (size_t)(kvh * G + g) * DA_D + s * 8);
+  const int n_rows = min(chunk, L - start);
+  const int n_steps = (n_rows + 15) >> 4;        // workgroup-uniform
   const bf16_t* csq = rope_cs + (size_t)(L - 1) * DA_D;
   const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + fc);
   const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + fc);
   u32x4_t kraw[DA_MAX_STEPS], vraw[DA_MAX_STEPS], craw[DA_MAX_STEPS], sraw[DA_MAX_STEPS];
-  const int n_steps = (end - start + 15) >> 4;      // workgroup-uniform
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
     if (it >= n_steps) break;
@@ -77,111 +96,97 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     sraw[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
   }
 
-  // ---- query heads of this kv head, rotated at position L-1 (the row just appended)
-  float qf[G][8];
+  // ---- stage the rotated query block (rows >= G are zero) ...
   {
-    float c[8], sn[8];
-    unpack8(qc, c);
-    unpack8(qs, sn);
+    u32x4_t outq = u32x4_t{0, 0, 0, 0};
+    u32x4_t rp;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      u32x4_t rp;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) rp[i] = __shfl_xor(qraw[g][i], 8, 64);
-      float x[8], xp[8];
-      unpack8(qraw[g], x);
-      unpack8(rp, xp);
-      rope8(x, xp, c, sn, upper, qf[g]);
+    for (int i = 0; i < 4; ++i) rp[i] = dpp_u<0x128>(qraw[i]);     // row_ror:8 == partner half of the same row
+    if (srow < G) {
+      float x[8], xp[8], cc[8], sn[8], o[8];
+      unpack8(qraw, x); unpack8(rp, xp); unpack8(qc, cc); unpack8(qs, sn);
+      rope8(x, xp, cc, sn, upper, o);
+      outq = pack8(o);
     }
+    *reinterpret_cast<u32x4_t*>(Qs + srow * DA_KLD + c * 8) = outq;
   }
-
-  float st_m[G], st_l[G], st_acc[G][8];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    st_m[g] = -1e30f;
-    st_l[g] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st_acc[g][i] = 0.f;
-  }
-
+  // ---- ... and the chunk's keys (rotated) and values; rows past the end are zero
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
     if (it >= n_steps) break;
-    const bool valid = start + it * 16 + wave * 4 + grp < end;
-    u32x4_t kpr;
+    const int lrow = it * 16 + srow;
+    u32x4_t kp4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kpr[i] = __shfl_xor(kraw[it][i], 8, 64);
-    float kx[8], kxp[8], c[8], sn[8], kr[8], vf[8];
-    unpack8(kraw[it], kx);
-    unpack8(kpr, kxp);
-    unpack8(craw[it], c);
-    unpack8(sraw[it], sn);
-    unpack8(vraw[it], vf);
-    rope8(kx, kxp, c, sn, upper, kr);
+    for (int i = 0; i < 4; ++i) kp4[i] = dpp_u<0x128>(kraw[it][i]);
+    float x[8], xp[8], cc[8], sn[8], o[8];
+    unpack8(kraw[it], x); unpack8(kp4, xp); unpack8(craw[it], cc); unpack8(sraw[it], sn);
+    rope8(x, xp, cc, sn, upper, o);
+    const bool ok = lrow < n_rows;
+    const u32x4_t z = u32x4_t{0, 0, 0, 0};
+    *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = ok ? pack8(o) : z;
+    *reinterpret_cast<u32x4_t*>(Vs + lrow * DA_VLD + c * 8) = ok ? vraw[it] : z;
+  }
+  __syncthreads();
+
+  // ---- wave w: 16-key tile w
+  const int fr = lane & 15, fq = lane >> 4;
+  float m_w = -1e30f, l_w = 0.f;
+  f32x4_t oacc[8];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float d = 0.f;
+  for (int dt = 0; dt < 8; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (wave < n_steps) {
+    f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 8; ++i) d = fmaf(qf[g][i], kr[i], d);
-      d += __shfl_xor(d, 1, 64);
-      d += __shfl_xor(d, 2, 64);
-      d += __shfl_xor(d, 4, 64);
-      d += __shfl_xor(d, 8, 64);
-      const float sc = valid ? d * scale : -1e30f;
-      const float mn = fmaxf(st_m[g], sc);
-      const float alpha = __expf(st_m[g] - mn);
-      const float p = valid ? __expf(sc - mn) : 0.f;
-      const float pb = rbf(p);
-      st_l[g] = st_l[g] * alpha + p;
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (wave * 16 + fr) * DA_KLD + ks * 32 + fq * 8);
+      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(Qs + fr * DA_KLD + ks * 32 + fq * 8);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, sacc, 0, 0, 0);
+    }
+    float sc[4], mx = -1e30f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) st_acc[g][i] = st_acc[g][i] * alpha + pb * vf[i];
-      st_m[g] = mn;
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = wave * 16 + fq * 4 + r < n_rows;
+      sc[r] = ok ? sacc[r] * scale : -1e30f;
+      mx = fmaxf(mx, sc[r]);
+    }
+    m_w = xor32_max(xor16_max(mx));
+    float p[8], rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = sc[r] > -1e29f ? __expf(sc[r] - m_w) : 0.f;
+      p[r + 4] = 0.f;
+      rs += p[r];
+    }
+    l_w = xor32_sum(xor16_sum(rs));
+    u32x4_t pk = pack8(p);
+    const bf16x8_t pb = *reinterpret_cast<bf16x8_t*>(&pk);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16_t* vr = Vs + (wave * 16 + fq * 4 + (fr >> 2)) * DA_VLD + dt * 16 + (fr & 3) * 4;
+      const v4s_da_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_da_t*)(vr));
+      const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], lo[0], lo[1], lo[2], lo[3]};   // upper k-slots meet P == 0
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
     }
   }
-
-  // ---- merge the 4 row groups of the wave (lanes s, s+16, s+32, s+48 hold the same d-chunk)
+  __syncthreads();          // every wave is done with Ks / Vs: the region becomes the merge buffer
+  if (fr < G) {
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      const float mo = __shfl_xor(st_m[g], off, 64);
-      const float lo = __shfl_xor(st_l[g], off, 64);
-      const float mn = fmaxf(st_m[g], mo);
-      const float a = __expf(st_m[g] - mn), b = __expf(mo - mn);
-      st_l[g] = st_l[g] * a + lo * b;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float ao = __shfl_xor(st_acc[g][i], off, 64);
-        st_acc[g][i] = st_acc[g][i] * a + ao * b;
-      }
-      st_m[g] = mn;
-    }
-  }
-
-  // ---- merge the 4 waves through LDS
-  __shared__ float sm_m[4][DA_GMAX], sm_l[4][DA_GMAX];
-  __shared__ __attribute__((aligned(16))) float sm_acc[4][G][DA_D];
-  if (grp == 0) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (s == 0) { sm_m[wave][g] = st_m[g]; sm_l[wave][g] = st_l[g]; }
-      *reinterpret_cast<f32x4_t*>(&sm_acc[wave][g][s * 8]) = f32x4_t{st_acc[g][0], st_acc[g][1], st_acc[g][2], st_acc[g][3]};
-      *reinterpret_cast<f32x4_t*>(&sm_acc[wave][g][s * 8 + 4]) = f32x4_t{st_acc[g][4], st_acc[g][5], st_acc[g][6], st_acc[g][7]};
-    }
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_D) + dt * 16 + fq * 4) = oacc[dt];
+    if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
   }
   __syncthreads();
   const size_t part = (size_t)blockIdx.x * Hq;
-  for (int idx = threadIdx.x; idx < G * DA_D; idx += 256) {
+  for (int idx = tid; idx < G * DA_D; idx += 256) {
     const int g = idx / DA_D, d = idx % DA_D;
-    float mn = sm_m[0][g];
+    float mn = Mm[g];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sm_m[w][g]);
+    for (int w = 1; w < 4; ++w) mn = fmaxf(mn, Mm[w * 16 + g]);
     float l = 0.f, a = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float e = __expf(sm_m[w][g] - mn);
-      l += sm_l[w][g] * e;
-      a += sm_acc[w][g][d] * e;
+      const float e = __expf(Mm[w * 16 + g] - mn);
+      l += Lm[w * 16 + g] * e;
+      a += Om[(w * 16 + g) * DA_D + d] * e;
     }
     const int hq = kvh * G + g;
     ws_acc[(part + hq) * DA_D + d] = a;
