@@ -229,11 +229,12 @@ __global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void argmax_finish_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
-                                                            int n_parts, unsigned char* seen, int* tok_buf, int* state, int advance_kv) {
+__global__ __launch_bounds__(1024) void argmax_finish_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                             int n_parts, unsigned char* seen, int* tok_buf, int* state, int advance_kv) {
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < n_parts; i += 256) {
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n_parts; i += 1024) {
     const float v = part_val[i];
     const int n = part_idx[i];
     if (v > best || (v == best && n < bi)) { best = v; bi = n; }
@@ -244,13 +245,13 @@ __global__ __launch_bounds__(256) void argmax_finish_kernel(const float* __restr
     const int oi = __shfl_xor(bi, o, 64);
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
-  __shared__ float sb[4];
-  __shared__ int si[4];
+  __shared__ float sb[16];
+  __shared__ int si[16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { sb[wave] = best; si[wave] = bi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 16; ++w)
       if (sb[w] > best || (sb[w] == best && si[w] < bi)) { best = sb[w]; bi = si[w]; }
     if (bi == 0x7fffffff) bi = 0;
     const int cur = state[1] + 1;
@@ -303,6 +304,6 @@ extern "C" int svlm_argmax_finish(const void* ws, int V, void* seen, int* tok_bu
   const int nb = (V + 4 * LM_ROWS - 1) / (4 * LM_ROWS);
   const float* pv = (const float*)ws;
   const int* pi = (const int*)(pv + nb);
-  argmax_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(pv, pi, nb, (unsigned char*)seen, tok_buf, state, advance_kv);
+  argmax_finish_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pv, pi, nb, (unsigned char*)seen, tok_buf, state, advance_kv);
   return svlm_check_launch("svlm_argmax_finish");
 }

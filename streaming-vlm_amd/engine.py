@@ -57,7 +57,7 @@ class SvlmEngine:
             # split-KV chunk: enough workgroups (n_splits * Hkv) to cover the chip at the bounded window
             target = max(1, 256 // tc.num_kv_heads)
             decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / target / 16))))
-        self.decode_chunk = int(decode_chunk)
+        self.decode_chunk = int(os.environ.get("SVLM_DECODE_CHUNK", decode_chunk))
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
         # EXPERIMENT, off by default: Infinity-Cache prefetch of layer l+1's weights on a side stream while layer l computes.
         # Measured on MI355X (2B, round 1): 52.7 ms/chunk with it vs 38.2 without -- the 27 fork/joins per step and the
