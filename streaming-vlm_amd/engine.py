@@ -54,9 +54,9 @@ class SvlmEngine:
         self.max_len = int(max_len)
         self.max_new = int(max_new_tokens)
         if decode_chunk is None:
-            # split-KV chunk: enough workgroups (n_splits * Hkv) to cover the chip at the bounded window
-            target = max(1, 256 // tc.num_kv_heads)
-            decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / target / 16))))
+            # split-KV chunk: ~64 splits per kv head at the bounded window (measured best on MI355X: 48 keys for
+            # 2B @ window 2048; fewer, fatter splits starve the chip, more of them bloat the combine)
+            decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / 64 / 16))))
         self.decode_chunk = int(os.environ.get("SVLM_DECODE_CHUNK", decode_chunk))
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
         # EXPERIMENT, off by default: Infinity-Cache prefetch of layer l+1's weights on a side stream while layer l computes.
