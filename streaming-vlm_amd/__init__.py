@@ -10,14 +10,12 @@ All arithmetic runs in ``libsvlm_hip.so`` (C ABI: include/svlm.h); importing the
 need a GPU, constructing an engine does and fails loudly otherwise.
 """
 from .config import ModelConfig, TextConfig, VisionConfig, qwen2_vl_2b, qwen2_vl_7b, tiny  # noqa: F401
-from .get_qwen_range import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range  # noqa: F401
-from .streaming_args import StreamingArgs  # noqa: F401
-from .vtt_utils import open_vtt, sec2ts  # noqa: F401
+from .spans import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range  # noqa: F401
 from .kv_pool import KVPool  # noqa: F401
 from .engine import SvlmEngine  # noqa: F401
-from .patch_model import StreamingQwen2VL, convert_qwen2_to_streaming, streaming_generate  # noqa: F401
-from .inference import (contiguous_id_and_kv, load_model_and_processor, process_past_kv, prune_id_and_kv_cache,  # noqa: F401
-                        resort_id_and_kv, sink_window_evict, streaming_inference)
+from .model import StreamingArgs, StreamingQwen2VL, convert_qwen2_to_streaming, streaming_generate  # noqa: F401
+from .driver import (contiguous_id_and_kv, load_model_and_processor, open_vtt, process_past_kv, prune_id_and_kv_cache,  # noqa: F401
+                     resort_id_and_kv, sec2ts, sink_window_evict, streaming_inference)
 from .synthetic import SyntheticProcessor, SyntheticVideo, patchify, synthetic_frame  # noqa: F401
 from .weights import random_state_dict  # noqa: F401
 

@@ -15,17 +15,16 @@ import json
 import os
 import sys
 import time
+from contextlib import contextmanager
 from typing import List, Optional
 
 import torch
 
 from .config import IM_END, VIDEO_PAD, VISION_END, VISION_START
-from .get_qwen_range import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range
+from .spans import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range
 from .kv_pool import KVPool
-from .patch_model import StreamingQwen2VL, convert_qwen2_to_streaming
-from .streaming_args import StreamingArgs
+from .model import StreamingArgs, StreamingQwen2VL, convert_qwen2_to_streaming
 from .synthetic import SyntheticProcessor, SyntheticVideo
-from .vtt_utils import open_vtt, sec2ts
 
 TOTAL_VIDEO_DURATION = 6000
 DEFAULT_CHUNK_DURATION = 1
@@ -37,6 +36,23 @@ DEFAULT_TEMPERATURE = 0.9
 DEFAULT_REPETITION_PENALTY = 1.05
 MAX_TOKEN_PER_DURATION = 20
 FPS = float(os.environ.get("QWENVL_FPS", "2.0"))       # the reference reads qwen_vl_utils.FPS (env-driven)
+
+
+# ----------------------------------------------------------------------------- WebVTT output (reference: utils/vtt_utils.py:5-16)
+@contextmanager
+def open_vtt(path):
+    """Append to `path`, writing the WEBVTT header first when the file is new."""
+    new = not os.path.exists(path)
+    with open(path, "w" if new else "a", encoding="utf-8") as f:
+        if new:
+            f.write("WEBVTT\n\n")
+        yield f
+
+
+def sec2ts(sec: float) -> str:
+    whole = int(sec)
+    ms = int((sec - whole) * 1000)
+    return f"{whole // 3600:02d}:{whole % 3600 // 60:02d}:{whole % 60:02d}.{ms:03d}"
 
 
 # ----------------------------------------------------------------------------- KV / id edits

@@ -15,7 +15,18 @@ import torch
 
 from .config import ModelConfig, from_hf_config
 from .engine import SvlmEngine
-from .streaming_args import StreamingArgs
+
+
+class StreamingArgs:
+    def __init__(self, pos_mode: str, all_text: bool = False):
+        if pos_mode not in ("append", "shrink"):
+            raise AssertionError("pos_mode must be in ['append', 'shrink']")
+        self.pos_mode = pos_mode          # "shrink": positions stay contiguous after eviction; "append": grow forever
+        self.all_text = all_text
+        self.input_ids = None             # full (pruned) ids of the stream; shrink mode derives positions from them
+        self.video_grid_thw = None        # cumulative, one row per chunk (never pruned, inference.py:415)
+        self.second_per_grid_ts = None
+        self.last_cache_position = -1
 
 
 def _grid_list(g):

@@ -133,3 +133,17 @@ def test_real_shape_2b_layer_stack_224():
     sd = random_state_dict(cfg, 0, "cpu")
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
     _compare(cfg, sd, 3, model, size=224, window=128)
+
+
+def test_full_size_2b_two_chunks_448():
+    """BASELINE configs[1] at FULL size: Qwen2-VL-2B (28 LLM layers, 32 ViT blocks), 448x448 frames (1024 patches ->
+    256 vision tokens), 2 chunks x 8 tokens, sink 4 / window 256 so that the second chunk evicts.  Same bars as the
+    tiny model: identical eviction trace, logits within 2.5x of the oracle's own tiling noise."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    from streaming_vlm_amd.weights import random_state_dict
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = C.qwen2_vl_2b()
+    sd = random_state_dict(cfg, 0, "cpu")
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
+    _compare(cfg, sd, 2, model, size=448, window=256, max_new=4)

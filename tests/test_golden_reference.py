@@ -12,7 +12,7 @@ from oracle import qwen_range as oqr
 from oracle.rope_index import get_rope_index as oracle_rope
 
 import streaming_vlm_amd as S
-from streaming_vlm_amd.get_qwen_range import all_ranges
+from streaming_vlm_amd.spans import all_ranges
 from streaming_vlm_amd.positions import rope_index_qwen2
 
 
