@@ -82,6 +82,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -1e30f, l_run = 0.f;
+  const float cexp = scale * 1.4426950408889634f;      // scale * log2(e)
 
   // keys needed by this workgroup
   int kmax = L;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       const int idx = tid + i * FA_THREADS;
       if (idx < FA_KT * CPR) {
         const int row = idx / CPR, c = idx % CPR;
-        const bool ok = kt * FA_KT + row < L;
+        const bool ok = kt * FA_KT + row < L;         // only the tile that crosses L zeroes anything
         *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = ok ? kreg[i] : z;
         *reinterpret_cast<u32x4_t*>(vt_ + row * FA_VLD + c * 8) = ok ? vreg[i] : z;      // V stays row-major: transposed on read
       }
@@ -134,29 +135,45 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
         sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], sacc[sub], 0, 0, 0);
       }
     }
-    // ---- online softmax for query column fr; this lane holds keys kt*32 + sub*16 + 4*fq + r
-    float sc[8];
-    float mx = -1e30f;
+    // ---- online softmax for query column fr; this lane holds keys kt*32 + sub*16 + 4*fq + r.
+    // Scores stay un-scaled until the exponent: p = exp2(s*c - m*c), c = scale*log2(e) (one FMA + v_exp per score).
+    // Masking runs only on tiles that touch the sequence end or the causal diagonal (wave-uniform test).
+    float sv[8];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = kt * FA_KT + sub * 16 + fq * 4 + r;
+      for (int r = 0; r < 4; ++r) sv[sub * 4 + r] = sacc[sub][r];
+    const int j_hi = kt * FA_KT + FA_KT - 1;
+    const bool need_mask = j_hi >= L || (causal && j_hi > qbase + causal_offset);      // qbase = smallest query of the wave
+    if (need_mask) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = kt * FA_KT + (i >> 2) * 16 + fq * 4 + (i & 3);
         const bool ok = j < L && (!causal || j <= tq + causal_offset);
-        const float s_ = ok ? sacc[sub][r] * scale : -1e30f;
-        sc[sub * 4 + r] = s_;
-        mx = fmaxf(mx, s_);
+        sv[i] = ok ? sv[i] : -1e30f;
       }
+    }
+    float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     mx = xor32_max(xor16_max(mx));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx);               // running max of the RAW scores
+    const float mc = m_new * cexp;
     float p[8], rs = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      p[i] = sc[i] > -1e29f ? __expf(sc[i] - m_new) : 0.f;
+      p[i] = exp2f(fmaf(sv[i], cexp, -mc));              // masked scores (-1e30) underflow to exactly 0
       rs += p[i];
     }
     rs = xor32_sum(xor16_sum(rs));
+    // rescale only when some query of the wave saw a new maximum (rare after the first tiles)
+    const bool grew = m_new > m_run;
+    float alpha = 1.f;
+    if (__any(grew)) {
+      alpha = exp2f((m_run - m_new) * cexp);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+    }
     l_run = l_run * alpha + rs;
     m_run = m_new;
     u32x4_t pk = pack8(p);
@@ -170,8 +187,6 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr));
       const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr + 16 * FA_VLD));
       const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
       oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
     }
   };
