@@ -196,7 +196,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         emit_json=False, time_test=False, *, kv_policy="structural", sink=4, window=2048, do_sample=True,
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
-                        generator=None, keep_logits=False, chunk_callback=None):
+                        generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True):
     def _sync():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -252,6 +252,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
     responses, time_results = [], []
     printq(f"num_chunks: {num_chunks}", quiet=quiet)
 
+    lookahead = None          # (frames, device patches, grid) of the next chunk, fetched one chunk early
     for i in range(num_chunks):
         if chunk_callback is not None:
             chunk_callback(i)
@@ -283,8 +284,9 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
 
         # ---- frames of this chunk
         _sync(); _t = time.perf_counter()
+        ahead, lookahead = lookahead, None
         try:
-            current_video_chunk = video.chunk(start_time, chunk_duration)
+            current_video_chunk = ahead[0] if ahead is not None else video.chunk(start_time, chunk_duration)
         except Exception as e:                          # the reference breaks the loop on a decode failure (:343-345)
             print(f"Error in streaming_inference: {e}")
             break
@@ -317,7 +319,17 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                 new_ids = torch.cat([prev_generated_ids, new_ids[:, 1:]], dim=1)
         inputs["input_ids"] = new_ids
         inputs["attention_mask"] = torch.ones_like(new_ids)
-        inputs["pixel_values_videos"] = inputs["pixel_values_videos"].to(device)
+        # the look-ahead handed these patches to the ViT already (same frames, same tensor object)
+        inputs["pixel_values_videos"] = ahead[1] if ahead is not None else inputs["pixel_values_videos"].to(device)
+        if vision_lookahead and not recompute and i + 1 < num_chunks:
+            # frames do not depend on the generated text: fetch the next chunk's now so its ViT pass can run underneath
+            # this chunk's decode steps (engine.vision_prefetch)
+            try:
+                nf = video.chunk(start_time + chunk_duration, chunk_duration)
+                nin = processor(text=["<|vision_start|><|video_pad|><|vision_end|>"], videos=nf, padding=True, return_tensors="pt")
+                lookahead = (nf, nin["pixel_values_videos"].to(device), nin["video_grid_thw"])
+            except Exception:
+                lookahead = None          # the regular path reports the failure when its turn comes
         recent_pixel_values_videos.append(inputs["pixel_values_videos"])
         streaming_args.input_ids = new_ids
         if i == 0:
@@ -332,6 +344,8 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         gen_kw = dict(max_new_tokens=max_new_tokens, use_cache=True, return_dict_in_generate=True, do_sample=do_sample,
                       repetition_penalty=repetition_penalty, streaming_args=streaming_args, pad_token_id=IM_END,
                       temperature=temperature, suppress_eos=suppress_eos, generator=generator, keep_logits=keep_logits)
+        if lookahead is not None:
+            gen_kw["next_vision"] = (lookahead[1], lookahead[2])
         if recompute:
             if past_key_values is not None:
                 past_key_values.release_reserved()

@@ -89,6 +89,8 @@ class SvlmEngine:
         self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, self.decode_chunk, dev)
         self.d_sws = ops.sampling_ws(V, dev)
         self._vit_rope_cache = {}
+        self._vis_stream = None            # side stream the NEXT chunk's ViT runs on while this chunk decodes
+        self._vis_pending = None           # (pixel tensor, grid, event, features)
         self._graph = None
         self._graph_key = None
         self._penalty = 1.0
@@ -153,6 +155,39 @@ class SvlmEngine:
         hm = h.view(N // m2, E * m2)
         g1 = o.gemm(hm, mg["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
         return o.gemm(g1, mg["w2"], bias=mg["b2"])
+
+    def vision_prefetch(self, pixel_values, grid_thw):
+        """Enqueue the ViT + merger of the NEXT chunk's frames on a side stream.  Frames do not depend on generated text,
+        so their encoding overlaps this chunk's decode steps (HBM/latency-bound GEMVs that leave the MFMA pipes idle).
+        The side stream starts after everything already enqueued on the current stream (this chunk's prefill: the two
+        never run GEMMs at the same time, so the split-K scratch is not shared) and `generate` of the next chunk waits
+        on the recorded event when it is handed the SAME pixel tensor."""
+        if self.device.type != "cuda":
+            return
+        if self._vis_stream is None:
+            # (stream priorities were measured and make no difference here: the device offers only normal/high and the
+            # decode workgroups are not dispatch-starved, they share HBM and CUs with the ViT tiles)
+            self._vis_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        self._vis_stream.wait_stream(main)
+        with torch.cuda.stream(self._vis_stream):
+            out = self.vision_forward(pixel_values, grid_thw)
+            ev = torch.cuda.Event()
+            ev.record(self._vis_stream)
+        grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
+        self._vis_pending = (pixel_values, grid, ev, out)
+
+    def _vision(self, pixel_values, grid_thw):
+        pend, self._vis_pending = self._vis_pending, None
+        if pend is not None:
+            grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
+            if pend[0] is pixel_values and pend[1] == grid:
+                main = torch.cuda.current_stream()
+                main.wait_event(pend[2])
+                pend[3].record_stream(main)
+                return pend[3]
+            pend[2].synchronize()          # stale look-ahead (caller changed its mind): let it drain, then recompute
+        return self.vision_forward(pixel_values, grid_thw)
 
     # ------------------------------------------------------------------ LLM
     def _prefill(self, c: KVPool, idx_dev, vis, T: int, L_before: int):
@@ -233,7 +268,9 @@ class SvlmEngine:
     # ------------------------------------------------------------------ generate
     def generate(self, ids: Sequence[int], cache: Optional[KVPool], video_grid_thw, pixel_values=None, grid_thw=None,
                  max_new_tokens: int = 20, repetition_penalty: float = 1.05, do_sample: bool = False, temperature: float = 1.0,
-                 suppress_eos: bool = False, keep_logits: bool = False, generator=None) -> GenerateOutput:
+                 suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None) -> GenerateOutput:
+        """`next_vision=(pixel_values, grid_thw)` of the FOLLOWING chunk, when the caller already has its frames, is
+        encoded on a side stream underneath this chunk's decode steps (see `vision_prefetch`)."""
         cfg, tc, o = self.cfg, self.cfg.text, self.ops
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
         if cache is None:
@@ -266,7 +303,7 @@ class SvlmEngine:
         if vmask.any():
             if pixel_values is None:
                 raise ValueError("video tokens in the un-cached suffix but no pixel_values_videos")
-            vis = self.vision_forward(pixel_values, grid_thw)
+            vis = self._vision(pixel_values, grid_thw)
             n_tok = int(vmask.sum())
             if n_tok != vis.shape[0]:
                 raise ValueError(f"Video features and video tokens do not match: tokens: {n_tok}, features {vis.shape[0]}")
@@ -287,8 +324,12 @@ class SvlmEngine:
         if keep_logits:
             logits_out.append(self.logits.detach().cpu().clone())
         if do_sample:
+            if next_vision is not None:
+                self.vision_prefetch(*next_vision)
             return self._generate_sampling(ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out)
         self._sample_launch(0)
+        if next_vision is not None:
+            self.vision_prefetch(*next_vision)
         for _ in range(1, max_new_tokens):
             self._decode_step(cache)
             if keep_logits:

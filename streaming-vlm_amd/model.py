@@ -39,7 +39,7 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
                        past_key_values=None, max_new_tokens: int = 20, use_cache: bool = True,
                        return_dict_in_generate: bool = True, do_sample: bool = True, repetition_penalty: float = 1.0,
                        streaming_args: Optional[StreamingArgs] = None, pad_token_id=None, temperature: float = 1.0,
-                       second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, **unused):
+                       second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None, **unused):
     """Greedy / sampling generation on the HIP engine (reference: streaming_generate + _sample,
     generate/streaming_generate_qwen.py:130-278, 8-127)."""
     eng: SvlmEngine = self._svlm_engine
@@ -52,7 +52,7 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     ids = input_ids[0].tolist()
     grids_all = _grid_list(streaming_args.video_grid_thw if streaming_args.video_grid_thw is not None else video_grid_thw)
     out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
-                       repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator)
+                       repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision)
     # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)
     if streaming_args.input_ids is not None:
         streaming_args.input_ids = torch.nn.functional.pad(streaming_args.input_ids, (0, out.n_new), "constant", 0)

@@ -112,6 +112,20 @@ def test_graph_replay_equals_eager_launches():
             assert torch.equal(x, y)
 
 
+def test_vision_lookahead_is_bitwise_neutral():
+    """Encoding chunk i+1's frames on the side stream under chunk i's decode steps must not change a single bit."""
+    outs = []
+    for ahead in (True, False):
+        cfg, sd, model = _tiny_model()
+        _, trace, counts, ids_log = H.run_engine_stream(model, 5, keep_logits=True, vision_lookahead=ahead)
+        outs.append((trace, ids_log))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert a["ids"] == b["ids"]
+        for x, y in zip(a["logits"], b["logits"]):
+            assert torch.equal(x, y)
+
+
 def test_eos_truncates_and_rolls_back_kv():
     import streaming_vlm_amd as S
     cfg, sd, model = _tiny_model()
