@@ -18,100 +18,116 @@
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
 
-// xs[0..K) = bf16( w * bf16(x * rsqrt(mean(x^2) + eps)) )  (NORM)  or a plain copy.  256 threads.
-template <bool NORM>
-__device__ __forceinline__ void stage_x(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps, int K, bf16_t* xs) {
+// The activation row is loaded ONCE, 8 elements per thread per chunk (XC chunks of 2048 cover K), together with the norm
+// gain, BEFORE the weight preloads are issued: vmcnt retires in order, so a wait for x placed behind the weight loads
+// would wait for the head of the weight stream as well.
+template <int XC>
+struct XRow {
+  u32x4_t x[XC], g[XC];
+};
+template <int XC>
+__device__ __forceinline__ void load_x(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, int K, XRow<XC>& xr) {
+#pragma unroll
+  for (int i = 0; i < XC; ++i) {
+    const int c = (i * 256 + threadIdx.x) * 8;
+    const int cc = c < K ? c : 0;
+    xr.x[i] = *reinterpret_cast<const u32x4_t*>(x + cc);
+    xr.g[i] = *reinterpret_cast<const u32x4_t*>(ln_w + cc);
+  }
+}
+
+// xs[0..K) = bf16( w * bf16(x * rsqrt(mean(x^2) + eps)) ), rounded exactly where the eager module rounds.  256 threads.
+// LDS-only barriers: the weight loads issued before this call stay in flight across them.
+template <int XC>
+__device__ __forceinline__ void stage_x(const XRow<XC>& xr, float eps, int K, bf16_t* xs) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
-  float r = 1.f;
-  if (NORM) {
-    float ss = 0.f;
-    for (int c = tid * 8; c < K; c += 2048) {
-      float f[8];
-      unpack8(*reinterpret_cast<const u32x4_t*>(x + c), f);
+  float f[XC][8];
+  float ss = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
-    }
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    r = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
-  }
-  for (int c = tid * 8; c < K; c += 2048) {
-    u32x4_t v = *reinterpret_cast<const u32x4_t*>(x + c);
-    if (NORM) {
-      float f[8], g[8];
-      unpack8(v, f);
-      unpack8(*reinterpret_cast<const u32x4_t*>(ln_w + c), g);
+  for (int i = 0; i < XC; ++i) {
+    unpack8(xr.x[i], f[i]);
+    if ((i * 256 + tid) * 8 < K) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] = g[i] * rbf(f[i] * r);
-      v = pack8(f);
+      for (int j = 0; j < 8; ++j) ss += f[i][j] * f[i][j];
     }
-    *reinterpret_cast<u32x4_t*>(xs + c) = v;
   }
-  __syncthreads();
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  lds_barrier();
+  const float r = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+#pragma unroll
+  for (int i = 0; i < XC; ++i) {
+    const int c = (i * 256 + tid) * 8;
+    if (c < K) {
+      float g[8];
+      unpack8(xr.g[i], g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = g[j] * rbf(f[i][j] * r);
+      *reinterpret_cast<u32x4_t*>(xs + c) = pack8(f[i]);
+    }
+  }
+  lds_barrier();
 }
 
 // The first PRE K-steps (512 elements each) of a wave's weight rows are requested BEFORE the activation row is
 // normalised and staged: weights do not depend on x, so the HBM latency of the stream's head overlaps the norm.
-#define DEC_PRE 2
-template <int NR>
+// PRE = 3 covers the whole row at K = 1536 (Qwen2-VL-2B); longer rows continue in fully pre-issued batches of PRE.
+template <int NR, int PRE>
 struct WPre {
-  u32x4_t w[DEC_PRE][NR];
+  u32x4_t w[PRE][NR];
 };
-template <int NR>
-__device__ __forceinline__ void preload_w(const bf16_t* const (&wr)[NR], int K, WPre<NR>& pre) {
+template <int NR, int PRE>
+__device__ __forceinline__ void preload_w(const bf16_t* const (&wr)[NR], int base, int K, WPre<NR, PRE>& pre) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int it = 0; it < DEC_PRE; ++it) {
-    const int c = min(it * 512 + lane * 8, K - 8);          // clamped (valid) address; unused when past K
+  for (int it = 0; it < PRE; ++it) {
+    const int c = base + it * 512 + lane * 8;
+    const int cc = c < K ? c : 0;                            // clamped (valid) address; its product is masked out
 #pragma unroll
-    for (int r = 0; r < NR; ++r) pre.w[it][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
+    for (int r = 0; r < NR; ++r) pre.w[it][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + cc));
   }
 }
 
-// acc[r] = W[row[r]] . xs   for NR rows of one wave
-template <int NR>
-__device__ __forceinline__ void wave_dots(const bf16_t* const (&wr)[NR], const bf16_t* xs, int K, float (&acc)[NR], const WPre<NR>& pre) {
+template <int NR, int PRE>
+__device__ __forceinline__ void fma_batch(const WPre<NR, PRE>& pre, const bf16_t* xs, int base, int K, float (&acc)[NR]) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int it = 0; it < DEC_PRE; ++it) {
-    const int c = it * 512 + lane * 8;
-    if (c < K) {
-      float xf[8];
-      unpack8(*reinterpret_cast<const u32x4_t*>(xs + c), xf);
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        float wf[8];
-        unpack8(pre.w[it][r], wf);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
-      }
-    }
-  }
-#pragma unroll 2
-  for (int c = DEC_PRE * 512 + lane * 8; c < K; c += 512) {
-    u32x4_t wv[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
+  for (int it = 0; it < PRE; ++it) {
+    const int c = base + it * 512 + lane * 8;
     float xf[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(xs + c), xf);
+    unpack8(*reinterpret_cast<const u32x4_t*>(xs + (c < K ? c : 0)), xf);
+    if (c >= K) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xf[i] = 0.f;
+    }
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       float wf[8];
-      unpack8(wv[r], wf);
+      unpack8(pre.w[it][r], wf);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
     }
+  }
+}
+
+// acc[r] = W[row[r]] . xs   for NR rows of one wave; `pre` holds K-steps [0, PRE) already in flight
+template <int NR, int PRE>
+__device__ __forceinline__ void wave_dots(const bf16_t* const (&wr)[NR], const bf16_t* xs, int K, float (&acc)[NR], WPre<NR, PRE>& pre) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) acc[r] = 0.f;
+  fma_batch<NR, PRE>(pre, xs, 0, K, acc);
+  for (int base = PRE * 512; base < K; base += PRE * 512) {
+    preload_w<NR, PRE>(wr, base, K, pre);
+    __builtin_amdgcn_sched_barrier(0);                       // every load of the batch is issued before its first FMA
+    fma_batch<NR, PRE>(pre, xs, base, K, acc);
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r) acc[r] = wave_sum(acc[r]);
 }
 
 // ---------------------------------------------------------------- QKV + KV append
-template <int ROWS>
+template <int ROWS, int PRE, int XC>
 __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
                                                       const bf16_t* __restrict__ W, int ldw, const bf16_t* __restrict__ bias,
                                                       bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_planes,
@@ -124,23 +140,27 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__
   const bf16_t* wr[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, N - 1) * ldw;
-  // everything that does not depend on x is requested first: head of the weight stream, the slot, the bias
-  WPre<ROWS> pre;
-  preload_w<ROWS>(wr, K, pre);
+  // x first, then everything that does not depend on it: head of the weight stream, the slot, the bias
+  XRow<XC> xr;
+  load_x<XC>(x, ln_w, K, xr);
+  __builtin_amdgcn_sched_barrier(0);
+  WPre<ROWS, PRE> pre;
+  preload_w<ROWS, PRE>(wr, 0, K, pre);
   const int slot = slot_of[len_dev ? *len_dev : len_host];
-  float bpre[ROWS];
+  bf16_t bpre[ROWS];
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) bpre[r] = bf2f(bias[min(n0 + r, N - 1)]);
-  stage_x<true>(x, ln_w, eps, K, xs);
+  for (int r = 0; r < ROWS; ++r) bpre[r] = bias[min(n0 + r, N - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  stage_x<XC>(xr, eps, K, xs);
   if (n0 >= N) return;
   float acc[ROWS];
-  wave_dots<ROWS>(wr, xs, K, acc, pre);
+  wave_dots<ROWS, PRE>(wr, xs, K, acc, pre);
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;
       if (n >= N) break;
-      const bf16_t v = f2bf(acc[r] + bpre[r]);
+      const bf16_t v = f2bf(acc[r] + bf2f(bpre[r]));
       if (n < qd) {
         q_out[n] = v;
       } else {
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__
 }
 
 // ---------------------------------------------------------------- gate/up + SwiGLU
-template <int ROWS>
+template <int ROWS, int PRE, int XC>
 __global__ __launch_bounds__(256) void dec_gate_up_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
                                                           const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ h, int I, int K) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
@@ -167,12 +187,16 @@ __global__ __launch_bounds__(256) void dec_gate_up_kernel(const bf16_t* __restri
     wr[r] = W + (size_t)n * ldw;               // gate row n
     wr[ROWS + r] = W + (size_t)(I + n) * ldw;  // up row n
   }
-  WPre<2 * ROWS> pre;
-  preload_w<2 * ROWS>(wr, K, pre);
-  stage_x<true>(x, ln_w, eps, K, xs);
+  XRow<XC> xr;
+  load_x<XC>(x, ln_w, K, xr);
+  __builtin_amdgcn_sched_barrier(0);
+  WPre<2 * ROWS, PRE> pre;
+  preload_w<2 * ROWS, PRE>(wr, 0, K, pre);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_x<XC>(xr, eps, K, xs);
   if (n0 >= I) return;
   float acc[2 * ROWS];
-  wave_dots<2 * ROWS>(wr, xs, K, acc, pre);
+  wave_dots<2 * ROWS, PRE>(wr, xs, K, acc, pre);
   if (lane == 0) {
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(256) void dec_gate_up_kernel(const bf16_t* __restri
 }
 
 // ---------------------------------------------------------------- lm_head + penalty + argmax candidates
-template <int ROWS>
+template <int ROWS, int PRE, int XC>
 __global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w, float eps,
                                                           const bf16_t* __restrict__ W, int ldw, float* __restrict__ logits,
                                                           const unsigned char* __restrict__ seen, float penalty,
@@ -197,14 +221,18 @@ __global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restri
   const bf16_t* wr[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) wr[r] = W + (size_t)min(n0 + r, V - 1) * ldw;
-  WPre<ROWS> pre;
-  preload_w<ROWS>(wr, K, pre);
-  stage_x<true>(x, ln_w, eps, K, xs);
+  XRow<XC> xr;
+  load_x<XC>(x, ln_w, K, xr);
+  __builtin_amdgcn_sched_barrier(0);
+  WPre<ROWS, PRE> pre;
+  preload_w<ROWS, PRE>(wr, 0, K, pre);
+  __builtin_amdgcn_sched_barrier(0);
+  stage_x<XC>(xr, eps, K, xs);
   float best = -INFINITY;
   int bi = 0x7fffffff;
   if (n0 < V) {
     float acc[ROWS];
-    wave_dots<ROWS>(wr, xs, K, acc, pre);
+    wave_dots<ROWS, PRE>(wr, xs, K, acc, pre);
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;
@@ -263,7 +291,17 @@ __global__ __launch_bounds__(1024) void argmax_finish_kernel(const float* __rest
 }
 
 // ================================================================ launchers
-static inline bool smem_ok(int K) { return K > 0 && K % 8 == 0 && K * 2 <= 64 * 1024; }
+static inline bool smem_ok(int K) { return K > 0 && K % 8 == 0 && K <= 8192; }
+
+// (PRE, XC) by row length: the whole row in one pre-issued batch at K <= 1536, batches of 4 K-steps beyond;
+// one 2048-element chunk of x per thread-pass
+#define DEC_DISPATCH(KERNEL, ROWS, K, ...)                                  \
+  do {                                                                      \
+    if ((K) <= 1536) KERNEL<ROWS, 3, 1> __VA_ARGS__;                        \
+    else if ((K) <= 2048) KERNEL<ROWS, 4, 1> __VA_ARGS__;                   \
+    else if ((K) <= 4096) KERNEL<ROWS, 4, 2> __VA_ARGS__;                   \
+    else KERNEL<ROWS, 4, 4> __VA_ARGS__;                                    \
+  } while (0)
 
 extern "C" int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out,
                             void* k_planes, void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd,
@@ -271,16 +309,16 @@ extern "C" int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const vo
   SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0, "svlm_dec_qkv: bad K=%d ldw=%d", K, ldw);
   SVLM_CHECK_ARG(qd > 0 && kd > 0 && D > 0 && kd % D == 0 && n_slots > 0 && bias != nullptr, "svlm_dec_qkv: bad qd=%d kd=%d D=%d", qd, kd, D);
   const int N = qd + 2 * kd;
-  dec_qkv_kernel<1><<<(N + 3) / 4, 256, K * 2, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw,
-                                                                      (const bf16_t*)bias, (bf16_t*)q_out, (bf16_t*)k_planes,
-                                                                      (bf16_t*)v_planes, slot_of, len_dev, len_host, N, K, qd, kd, D, n_slots);
+  DEC_DISPATCH(dec_qkv_kernel, 1, K, <<<(N + 3) / 4, 256, K * 2, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)q_out, (bf16_t*)k_planes,
+      (bf16_t*)v_planes, slot_of, len_dev, len_host, N, K, qd, kd, D, n_slots));
   return svlm_check_launch("svlm_dec_qkv");
 }
 
 extern "C" int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, const void* W, int ldw, void* h, int I, int K, void* stream) {
   SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0 && I > 0, "svlm_dec_gate_up: bad I=%d K=%d ldw=%d", I, K, ldw);
-  dec_gate_up_kernel<2><<<(I + 7) / 8, 256, K * 2, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw,
-                                                                         (bf16_t*)h, I, K);
+  DEC_DISPATCH(dec_gate_up_kernel, 2, K, <<<(I + 7) / 8, 256, K * 2, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, (bf16_t*)h, I, K));
   return svlm_check_launch("svlm_dec_gate_up");
 }
 
@@ -294,8 +332,9 @@ extern "C" int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, cons
   const int nb = (V + 4 * LM_ROWS - 1) / (4 * LM_ROWS);
   float* pv = (float*)ws;
   int* pi = (int*)(pv + nb);
-  dec_lm_head_kernel<LM_ROWS><<<nb, 256, K * 2, (hipStream_t)stream>>>((const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, logits,
-                                                                       (const unsigned char*)seen, penalty, suppress, n_suppress, pv, pi, V, K);
+  DEC_DISPATCH(dec_lm_head_kernel, LM_ROWS, K, <<<nb, 256, K * 2, (hipStream_t)stream>>>(
+      (const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, logits, (const unsigned char*)seen, penalty, suppress,
+      n_suppress, pv, pi, V, K));
   return svlm_check_launch("svlm_dec_lm_head");
 }
 

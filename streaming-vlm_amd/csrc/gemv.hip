@@ -21,48 +21,43 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     n = n < N ? n : N - 1;
     wr[r] = W + (size_t)n * ldw;
   }
-  float acc[ROWS], epi[ROWS];
+  float acc[ROWS];
+  bf16_t epi_raw[ROWS], bia_raw[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     acc[r] = 0.f;
-    // residual / bias are requested up front so that their latency hides under the weight stream
+    // residual / bias are requested up front, branch-free (null -> x[0]) and converted only in the epilogue, so that
+    // their latency hides under the weight stream
     const int n = min(n0 + r, N - 1);
-    epi[r] = (residual ? bf2f(residual[n]) : 0.f);
-    acc[r] = 0.f;
+    epi_raw[r] = (residual ? residual : x)[residual ? n : 0];
+    bia_raw[r] = (bias ? bias : x)[bias ? n : 0];
   }
-  float bia[ROWS];
+  // all 16-B loads of a batch are in flight before the first FMA; lanes past K load a clamped address and see x = 0
+  constexpr int PRE = ROWS >= 4 ? 3 : 4;
+  for (int base = 0; base < K; base += PRE * 512) {
+    u32x4_t xv[PRE], wv[PRE][ROWS];
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) bia[r] = bias ? bf2f(bias[min(n0 + r, N - 1)]) : 0.f;
-
-  const int nfull = K / 512;
-#pragma unroll 2
-  for (int it = 0; it < nfull; ++it) {
-    const int c = it * 512 + lane * 8;
-    u32x4_t xv = *reinterpret_cast<const u32x4_t*>(x + c);
-    u32x4_t wv[ROWS];
+    for (int it = 0; it < PRE; ++it) {
+      const int c = base + it * 512 + lane * 8;
+      const int cc = c < K ? c : 0;
+      xv[it] = *reinterpret_cast<const u32x4_t*>(x + cc);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
-    float xf[8];
-    unpack8(xv, xf);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      float wf[8];
-      unpack8(wv[r], wf);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
+      for (int r = 0; r < ROWS; ++r) wv[it][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + cc));
     }
-  }
-  {
-    const int c = nfull * 512 + lane * 8;
-    if (c < K) {
-      u32x4_t xv = *reinterpret_cast<const u32x4_t*>(x + c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+      const int c = base + it * 512 + lane * 8;
       float xf[8];
-      unpack8(xv, xf);
+      unpack8(xv[it], xf);
+      if (c >= K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[i] = 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-        u32x4_t wv = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c));
         float wf[8];
-        unpack8(wv, wf);
+        unpack8(wv[it][r], wf);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
       }
@@ -75,9 +70,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict
     for (int r = 0; r < ROWS; ++r) {
       const int n = n0 + r;
       if (n >= N) break;
-      float v = acc[r] + bia[r];
+      float v = acc[r] + (bias ? bf2f(bia_raw[r]) : 0.f);
       v = apply_act(rbf(v), act);
-      if (residual) v = rbf(v + epi[r]);
+      if (residual) v = rbf(v + bf2f(epi_raw[r]));
       if (y) y[n] = f2bf(v);
       if (y_f32) y_f32[n] = v;
     }
@@ -100,23 +95,42 @@ __global__ __launch_bounds__(256) void gemv_bf16_ksplit_kernel(const bf16_t* __r
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  // epilogue operands requested up front (their latency hides under the weight stream)
-  float epi = 0.f, bia = 0.f;
-  if (threadIdx.x < ROWS) {
-    const int n = min(n0 + (int)threadIdx.x, N - 1);
-    if (residual) epi = bf2f(residual[n]);
-    if (bias) bia = bf2f(bias[n]);
-  }
-#pragma unroll 4
-  for (int c = k_lo + lane * 8; c < k_hi; c += 512) {
-    float xf[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(x + c), xf);
+  // epilogue operands requested up front, unconditionally (a null pointer is redirected to x so that the load stays
+  // branch-free and is only WAITED for in the epilogue: its latency hides under the weight stream)
+  const int ne = min(n0 + (int)(threadIdx.x % ROWS), N - 1);
+  const bf16_t epi_raw = (residual ? residual : x)[residual ? ne : 0];
+  const bf16_t bia_raw = (bias ? bias : x)[bias ? ne : 0];
+  // Every 16-B load of a batch is issued before the first FMA (a lane-variant `c < k_hi` loop bound makes the compiler
+  // wait for each iteration's loads before it issues the next ones: 2-3 KB in flight per wave instead of ~15).
+  // Lanes past the end of the wave's K range load a clamped (valid) address and multiply by a zeroed x chunk.
+  constexpr int PRE = 5;
+  for (int base = k_lo; base < k_hi; base += PRE * 512) {
+    u32x4_t xv[PRE], wv[PRE][ROWS];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      float wf[8];
-      unpack8(__builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + c)), wf);
+    for (int it = 0; it < PRE; ++it) {
+      const int c = base + it * 512 + lane * 8;
+      const int cc = c < k_hi ? c : k_lo;
+      xv[it] = *reinterpret_cast<const u32x4_t*>(x + cc);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
+      for (int r = 0; r < ROWS; ++r) wv[it][r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr[r] + cc));
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep the unpack/FMA of early chunks from sinking between the load issues
+#pragma unroll
+    for (int it = 0; it < PRE; ++it) {
+      const int c = base + it * 512 + lane * 8;
+      float xf[8];
+      unpack8(xv[it], xf);
+      if (c >= k_hi) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xf[i] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        float wf[8];
+        unpack8(wv[it][r], wf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r] = fmaf(wf[i], xf[i], acc[r]);
+      }
     }
   }
   __shared__ float part[4][ROWS];
@@ -129,9 +143,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_ksplit_kernel(const bf16_t* __r
   if (threadIdx.x < ROWS) {
     const int r = threadIdx.x, n = n0 + r;
     if (n < N) {
-      float v = part[0][r] + part[1][r] + part[2][r] + part[3][r] + bia;
+      float v = part[0][r] + part[1][r] + part[2][r] + part[3][r] + (bias ? bf2f(bia_raw) : 0.f);
       v = apply_act(rbf(v), act);
-      if (residual) v = rbf(v + epi);
+      if (residual) v = rbf(v + bf2f(epi_raw));
       if (y) y[n] = f2bf(v);
       if (y_f32) y_f32[n] = v;
     }

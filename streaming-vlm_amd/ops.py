@@ -18,7 +18,14 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    # raw handle of torch's current stream; the C accessor is ~20x cheaper than building a torch.cuda.Stream object
+    # (a prefill is ~300 launches from Python, so this is per-chunk host time the GPU can end up waiting for)
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
