@@ -35,7 +35,8 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     const bf16_t* __restrict__ q, long q_row_stride, long q_head_stride, long q_seq_stride,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long kv_row_stride, long kv_head_stride, long kv_seq_stride,
     bf16_t* __restrict__ out, long o_row_stride, long o_head_stride, long o_seq_stride,
-    int T, int L, int causal_offset, int causal, int Hq, int Hkv, float scale) {
+    int T, int L, int causal_offset, int causal, int Hq, int Hkv, float scale,
+    int n_split, float* __restrict__ part_o, float* __restrict__ part_ml) {
   constexpr int KLD = DP + 8;          // K LDS row stride (bf16): 272 B / 208 B, conflict-free ds_read_b128
   constexpr int CPR = D / 8;           // 16-B chunks per row
   constexpr int NKS = DP / 32;         // k-steps of the QK^T product
@@ -48,7 +49,10 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int seq = blockIdx.z, head = blockIdx.y;
+  // n_split > 1 (prefill only, one sequence): blockIdx.z is the key split; each split covers an even number of this
+  // workgroup's key tiles and leaves un-normalised (O, m, l) partials for flash_combine_kernel
+  const int seq = n_split > 1 ? 0 : blockIdx.z, head = blockIdx.y;
+  const int sp = n_split > 1 ? blockIdx.z : 0;
   const int kvh = head / (Hq / Hkv);
   const int qbase = (blockIdx.x * 4 + wave) * 16;
   q += seq * q_seq_stride;
@@ -87,7 +91,10 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   // keys needed by this workgroup
   int kmax = L;
   if (causal) kmax = min(L, min(blockIdx.x * 64 + 63, T - 1) + causal_offset + 1);
-  const int n_kt = (kmax + FA_KT - 1) / FA_KT;
+  const int n_kt_all = (kmax + FA_KT - 1) / FA_KT;
+  const int per = ((n_kt_all + n_split - 1) / n_split + 1) & ~1;      // even: the stage parity below starts at 0
+  const int kt_lo = sp * per;
+  const int n_kt = min(n_kt_all, kt_lo + per);
 
   // ---- staging: thread owns chunks idx = tid + i*256 of every tile; two register slots form a ring so that the
   // global loads of tile t+3 are in flight while tile t is computed (one barrier per tile, two iterations to land)
@@ -145,12 +152,15 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       for (int r = 0; r < 4; ++r) sv[sub * 4 + r] = sacc[sub][r];
     const int j_hi = kt * FA_KT + FA_KT - 1;
     const bool need_mask = j_hi >= L || (causal && j_hi > qbase + causal_offset);      // qbase = smallest query of the wave
+    unsigned okbits = 0xFFu;
     if (need_mask) {
+      okbits = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = kt * FA_KT + (i >> 2) * 16 + fq * 4 + (i & 3);
         const bool ok = j < L && (!causal || j <= tq + causal_offset);
         sv[i] = ok ? sv[i] : -1e30f;
+        okbits |= ok ? (1u << i) : 0u;
       }
     }
     float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
@@ -160,9 +170,14 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     float p[8], rs = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      p[i] = exp2f(fmaf(sv[i], cexp, -mc));              // masked scores (-1e30) underflow to exactly 0
-      rs += p[i];
+      p[i] = exp2f(fmaf(sv[i], cexp, -mc));              // masked scores (-1e30) underflow to exactly 0 ...
     }
+    if (need_mask) {                                     // ... unless the whole row is masked so far (a key split that
+#pragma unroll                                           // starts beyond a query's causal limit): m is still -1e30 there
+      for (int i = 0; i < 8; ++i) p[i] = (okbits >> i) & 1u ? p[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rs += p[i];
     rs = xor32_sum(xor16_sum(rs));
     // rescale only when some query of the wave saw a new maximum (rare after the first tiles)
     const bool grew = m_new > m_run;
@@ -191,13 +206,13 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     }
   };
 
-  load_tile(0, kr0, vr0);
-  load_tile(1, kr1, vr1);
+  load_tile(kt_lo, kr0, vr0);
+  load_tile(kt_lo + 1, kr1, vr1);
   __syncthreads();          // pad zeroing visible before the first K store lands next to it
-  store_tile(0, 0, kr0, vr0);
-  load_tile(2, kr0, vr0);
+  store_tile(0, kt_lo, kr0, vr0);
+  load_tile(kt_lo + 2, kr0, vr0);
   __syncthreads();
-  for (int kt = 0; kt < n_kt; kt += 2) {
+  for (int kt = kt_lo; kt < n_kt; kt += 2) {
     // even: stage 0 holds tile kt; slot 1 holds kt+1, slot 0 holds kt+2
     if (kt + 1 < n_kt) store_tile(1, kt + 1, kr1, vr1);
     load_tile(kt + 3, kr1, vr1);
@@ -214,6 +229,19 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   }
 
   // ---- epilogue: lane holds O[tq][dt*16 + 4*fq + r]
+  if (n_split > 1) {
+    if (tq < T) {
+      const size_t row = ((size_t)sp * T + tq) * Hq + head;
+      float* po = part_o + row * D;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<f32x4_t*>(po + dt * 16 + fq * 4) = oacc[dt];
+      if (fq == 0) {
+        part_ml[row * 2] = m_run;
+        part_ml[row * 2 + 1] = l_run;
+      }
+    }
+    return;
+  }
   if (tq < T) {
     const float inv = 1.0f / l_run;
     bf16_t* orow = out + (size_t)tq * o_row_stride + (size_t)head * o_head_stride;
@@ -225,6 +253,58 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       *reinterpret_cast<u32x2_t*>(orow + dt * 16 + fq * 4) = o;
     }
   }
+}
+
+// Merge of the key splits: out[t][h][:] = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max_s m_s) * scale*log2 e).
+// One thread per (t, h, 4 consecutive d).
+__global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                            bf16_t* __restrict__ out, long o_row_stride, int T, int Hq, int n_split,
+                                                            float scale) {
+  constexpr int D = 128;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)T * Hq * (D / 4)) return;
+  const int c = (int)(i % (D / 4));
+  const long th = i / (D / 4);                       // t * Hq + h
+  const float cexp = scale * 1.4426950408889634f;
+  float m[8], l[8];
+  f32x4_t o[8];
+  float M = -1e30f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < n_split) {
+      const size_t row = (size_t)s * T * Hq + th;
+      m[s] = part_ml[row * 2];
+      l[s] = part_ml[row * 2 + 1];
+      o[s] = *reinterpret_cast<const f32x4_t*>(part_o + row * D + c * 4);
+      M = fmaxf(M, m[s]);
+    }
+  }
+  float Ls = 0.f;
+  f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s < n_split) {
+      const float w = exp2f((m[s] - M) * cexp);      // an empty split has l = 0 and O = 0
+      Ls += w * l[s];
+      acc += o[s] * w;
+    }
+  }
+  const float inv = 1.0f / Ls;
+  const int t = (int)(th / Hq), h = (int)(th % Hq);
+  u32x2_t r;
+  r[0] = pack2(acc[0] * inv, acc[1] * inv);
+  r[1] = pack2(acc[2] * inv, acc[3] * inv);
+  *reinterpret_cast<u32x2_t*>(out + (size_t)t * o_row_stride + h * D + c * 4) = r;
+}
+
+// Key splits of a prefill: enough workgroups to cover the chip (a 290-row chunk of a 12-head model is 60 query tiles),
+// at least four 32-key tiles per split, at most 8.
+static inline int prefill_splits(int T, int L, int Hq) {
+  const int base = ((T + 63) / 64) * Hq;
+  int ns = base > 0 ? 256 / base : 1;
+  const int by_len = L / (4 * FA_KT);
+  ns = ns < by_len ? ns : by_len;
+  return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
 }
 
 // K: gather + rotate; V: gather; Q: rotate.  D = 128; one thread per 16-B chunk.
@@ -278,10 +358,11 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
   }
 }
 
-// workspace: q_rot (T*Hq*128) | k_rot (Hkv*L*128) | v_lin (Hkv*L*128)  bf16
+// workspace: q_rot (T*Hq*128) | k_rot (Hkv*L*128) | v_lin (Hkv*L*128)  bf16 | split partials O (ns*T*Hq*128) | m,l (ns*T*Hq*2) fp32
 extern "C" long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv) {
   if (T < 0 || L < 0 || Hq <= 0 || Hkv <= 0) return SVLM_EINVAL;
-  return ((long long)T * Hq + 2LL * Hkv * L) * 128 * 2;
+  const int ns = prefill_splits(T, L, Hq);
+  return ((long long)T * Hq + 2LL * Hkv * L) * 128 * 2 + (ns > 1 ? (long long)ns * T * Hq * (128 + 2) * 4 : 0);
 }
 
 // LLM prefill: q (T, Hq*128) un-rotated rows, pool planes of one layer, out (T, Hq*128).
@@ -305,10 +386,17 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
                                        (const bf16_t*)rope_cs, q_rot, k_rot, v_lin, T, L, Hq, Hkv, n_slots);
   int rc = svlm_check_launch("svlm_prefill_attn_ropeload(rope_gather)");
   if (rc) return rc;
-  dim3 grid((T + 63) / 64, Hq, 1);
+  const int ns = prefill_splits(T, L, Hq);
+  float* part_o = (float*)(v_lin + (size_t)Hkv * L * 128);
+  float* part_ml = part_o + (size_t)ns * T * Hq * 128;
+  dim3 grid((T + 63) / 64, Hq, ns);
   flash_attn_kernel<128, 128><<<grid, FA_THREADS, 0, st>>>(q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out,
-                                                           o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv, scale);
-  return svlm_check_launch("svlm_prefill_attn_ropeload");
+                                                           o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv, scale, ns, part_o, part_ml);
+  rc = svlm_check_launch("svlm_prefill_attn_ropeload");
+  if (rc || ns == 1) return rc;
+  const long n_thr = (long)T * Hq * 32;
+  flash_combine_kernel<<<(int)((n_thr + 255) / 256), 256, 0, st>>>(part_o, part_ml, (bf16_t*)out, o_stride, T, Hq, ns, scale);
+  return svlm_check_launch("svlm_prefill_attn_ropeload(combine)");
 }
 
 // ViT: qkv (N, 3, H, d) fused buffer already rotated by svlm_vit_rope; n_seq sequences of seq_len rows.
@@ -322,11 +410,11 @@ extern "C" int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len,
   if (d == 80) {
     flash_attn_kernel<80, 96><<<grid, FA_THREADS, 0, (hipStream_t)stream>>>(
         base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,
-        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale);
+        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale, 1, nullptr, nullptr);
   } else {
     flash_attn_kernel<128, 128><<<grid, FA_THREADS, 0, (hipStream_t)stream>>>(
         base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,
-        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale);
+        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale, 1, nullptr, nullptr);
   }
   return svlm_check_launch("svlm_vit_attn");
 }
