@@ -196,73 +196,70 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 
 // One workgroup per q head; wave w merges splits w, w+4, ... with 4 loads in flight per lane, then the
 // waves merge through LDS.  Lane owns d = 2*lane, 2*lane+1.
-__global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
-                                                                  const float* __restrict__ ws_acc, const int* __restrict__ len_dev,
-                                                                  int len_add, bf16_t* __restrict__ out, int Hq, int chunk) {
+// NW waves per head; wave w merges splits w, w+NW, ... in batches of CB whose loads are ALL issued before anything is
+// consumed (the partials were written by other CUs: every dependent round trip here is ~1-2 us of L2/fabric latency, and the
+// kernel is nothing but such round trips).  43 splits (2k keys) on 4 waves = one batch.
+#define DA_CB 12
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
+                                                                      const float* __restrict__ ws_acc, const int* __restrict__ len_dev,
+                                                                      int len_add, bf16_t* __restrict__ out, int Hq, int chunk) {
   const int L = (len_dev ? *len_dev : 0) + len_add;
   const int ns = (L + chunk - 1) / chunk;
   const int hq = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // first batch of this wave's partials is requested before anything depends on the global max
-  float m_[4], l_[4];
-  float2 v_[4];
+  float m_[DA_CB], l_[DA_CB];
+  float2 v_[DA_CB];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i0 = min(wave + 4 * u, ns - 1);
+  for (int u = 0; u < DA_CB; ++u) {
+    const int i0 = min(wave + NW * u, ns - 1);
     const size_t p = (size_t)i0 * Hq + hq;
     m_[u] = ws_m[p];
     l_[u] = ws_l[p];
     v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + 2 * lane);
   }
-  // global max over splits (every wave computes it redundantly: ns floats, L2-resident)
+  // global max over splits (every wave computes it redundantly: ns floats)
   float mx = -1e30f;
   for (int i = lane; i < ns; i += 64) mx = fmaxf(mx, ws_m[(size_t)i * Hq + hq]);
+  __builtin_amdgcn_sched_barrier(0);
   mx = wave_max(mx);
   float l = 0.f, a0 = 0.f, a1 = 0.f;
+  for (int base = 0;;) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (wave + 4 * u < ns) {
-      const float e = __expf(m_[u] - mx);
-      l += l_[u] * e;
-      a0 += v_[u].x * e;
-      a1 += v_[u].y * e;
+    for (int u = 0; u < DA_CB; ++u) {
+      if (base + wave + NW * u < ns) {
+        const float e = __expf(m_[u] - mx);
+        l += l_[u] * e;
+        a0 += v_[u].x * e;
+        a1 += v_[u].y * e;
+      }
     }
-  }
-  int i = wave + 16;
-  for (; i + 12 < ns; i += 16) {
+    base += NW * DA_CB;
+    if (base >= ns) break;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t p = (size_t)(i + 4 * u) * Hq + hq;
+    for (int u = 0; u < DA_CB; ++u) {
+      const int i0 = min(base + wave + NW * u, ns - 1);
+      const size_t p = (size_t)i0 * Hq + hq;
       m_[u] = ws_m[p];
       l_[u] = ws_l[p];
       v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + 2 * lane);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float e = __expf(m_[u] - mx);
-      l += l_[u] * e;
-      a0 += v_[u].x * e;
-      a1 += v_[u].y * e;
-    }
+    __builtin_amdgcn_sched_barrier(0);
   }
-  for (; i < ns; i += 4) {
-    const size_t p = (size_t)i * Hq + hq;
-    const float e = __expf(ws_m[p] - mx);
-    const float2 v = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + 2 * lane);
-    l += ws_l[p] * e;
-    a0 += v.x * e;
-    a1 += v.y * e;
-  }
-  __shared__ float sl[4];
-  __shared__ float sa[4][DA_D];
+  __shared__ float sl[NW];
+  __shared__ float sa[NW][DA_D];
   if (lane == 0) sl[wave] = l;
   sa[wave][2 * lane] = a0;
   sa[wave][2 * lane + 1] = a1;
   __syncthreads();
   if (threadIdx.x < DA_D) {
     const int d = threadIdx.x;
-    const float lt = sl[0] + sl[1] + sl[2] + sl[3];
-    const float at = sa[0][d] + sa[1][d] + sa[2][d] + sa[3][d];
+    float lt = 0.f, at = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      lt += sl[w];
+      at += sa[w][d];
+    }
     out[(size_t)hq * DA_D + d] = f2bf(at / lt);
   }
 }
@@ -304,6 +301,9 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
 #undef SVLM_DA_CASE
   int rc = svlm_check_launch("svlm_decode_attn_ropeload(split)");
   if (rc) return rc;
-  decode_attn_combine_kernel<<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+  if ((max_len + chunk - 1) / chunk <= 4 * DA_CB * 2)      // up to two batches per wave: 4 waves; long caches: 16
+    decode_attn_combine_kernel<4><<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+  else
+    decode_attn_combine_kernel<16><<<Hq, 1024, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
   return svlm_check_launch("svlm_decode_attn_ropeload(combine)");
 }
