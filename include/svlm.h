@@ -107,7 +107,8 @@ int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v
                               int max_len, int chunk, float scale, void* stream);
 /* Prefill attention: q (T, q_stride) un-rotated rows for logical positions L-T..L-1 (their K/V already
  * appended), causal bottom-right aligned; out (T, o_stride); ws >= svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv)
- * holds the rotated queries and this layer's rotated keys / gathered values in logical order.
+ * holds the rotated queries, this layer's rotated keys / gathered values in logical order and, when the
+ * query tiles alone cannot fill the chip, the fp32 (O, m, l) partials of up to 8 key splits.
  * replaces: same lines at q_len = T. */
 long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv);
 int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_planes, const void* v_planes, const int* slot_of,

@@ -197,8 +197,12 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
                         generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True):
+    # The reference synchronises the device around every section to print per-section times.  Nobody reads them when the
+    # loop is quiet and not under time_test, and each of the dozen syncs per chunk is host time the GPU spends idle.
+    timed_sections = time_test or not quiet
+
     def _sync():
-        if torch.cuda.is_available():
+        if timed_sections and torch.cuda.is_available():
             torch.cuda.synchronize()
 
     if window_size % chunk_duration:
