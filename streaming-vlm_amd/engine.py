@@ -38,6 +38,56 @@ class GenerateOutput:
     n_new: int = 0
 
 
+class _VitRun:
+    """One ViT + merger pass in resumable stages (patch embed at construction, `blocks(lo, hi)`, `finish()`), so that a
+    look-ahead pass can be cut in two: most blocks underneath the current chunk's decode steps, the tail in the host
+    turnaround between chunks when the GPU has nothing else to do."""
+
+    def __init__(self, eng, pixel_values, grid_thw):
+        o, w, vc = eng.ops, eng.w, eng.cfg.vision
+        grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
+        N = sum(t * h * ww for t, h, ww in grid)
+        if pixel_values.shape[0] != N or pixel_values.shape[1] != vc.patch_dim:
+            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {grid} (N={N}, patch_dim={vc.patch_dim})")
+        sizes = {h * ww for _, h, ww in grid}
+        if len(sizes) != 1:
+            raise ValueError("all temporal grids of one call must share h*w")
+        self.eng, self.N = eng, N
+        self.seq_len = sizes.pop()
+        self.n_seq = N // self.seq_len
+        pix = pixel_values.to(device=eng.device, dtype=BF16).contiguous()
+        self.cosT, self.sinT = eng._vit_rope(grid)
+        E = vc.embed_dim
+        self.x = o.gemm(pix, w.patch_embed)
+        self.h = torch.empty_like(self.x)
+        self.qkv = torch.empty((N, 3 * E), dtype=BF16, device=eng.device)
+        self.a = torch.empty((N, E), dtype=BF16, device=eng.device)
+        self.f = torch.empty((N, vc.mlp_hidden), dtype=BF16, device=eng.device)
+
+    def blocks(self, lo: int, hi: int):
+        o, vc = self.eng.ops, self.eng.cfg.vision
+        Hh, d = vc.num_heads, vc.head_dim
+        scale = 1.0 / math.sqrt(d)
+        x, h, qkv, a, f = self.x, self.h, self.qkv, self.a, self.f
+        for bw in self.eng.w.vit[lo:hi]:
+            o.layernorm(x, bw["n1w"], bw["n1b"], 1e-6, out=h)
+            o.gemm(h, bw["qkv_w"], bias=bw["qkv_b"], out=qkv)
+            o.vit_rope(qkv, self.cosT, self.sinT, Hh, d)
+            o.vit_attn(qkv, self.n_seq, self.seq_len, Hh, d, scale, out=a)
+            o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
+            o.layernorm(x, bw["n2w"], bw["n2b"], 1e-6, out=h)
+            o.gemm(h, bw["fc1_w"], bias=bw["fc1_b"], out=f, act=ACT_QUICK_GELU)
+            o.gemm(f, bw["fc2_w"], bias=bw["fc2_b"], residual=x, out=x)
+
+    def finish(self):
+        o, vc, mg = self.eng.ops, self.eng.cfg.vision, self.eng.w.merger
+        o.layernorm(self.x, mg["ln_w"], mg["ln_b"], 1e-6, out=self.h)
+        m2 = vc.spatial_merge_size ** 2
+        hm = self.h.view(self.N // m2, vc.embed_dim * m2)
+        g1 = o.gemm(hm, mg["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
+        return o.gemm(g1, mg["w2"], bias=mg["b2"])
+
+
 class SvlmEngine:
     def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, max_len: int = 4096, max_new_tokens: int = 32,
                  decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None):
@@ -74,6 +124,9 @@ class SvlmEngine:
         self.rope_cs = torch.zeros((self.max_len, tc.head_dim), dtype=BF16, device=dev)
         # sampling / feedback state
         self.tok_buf = torch.zeros(self.max_new + 1, dtype=torch.int32, device=dev)
+        if dev.type == "cuda":
+            self._tok_host = torch.zeros(self.max_new + 1, dtype=torch.int32).pin_memory()
+            self._tok_ev = torch.cuda.Event()
         self.state = torch.zeros(2, dtype=torch.int32, device=dev)          # [kv_len, cur]
         self.seen = torch.zeros(V, dtype=torch.uint8, device=dev)
         self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
@@ -90,7 +143,9 @@ class SvlmEngine:
         self.d_sws = ops.sampling_ws(V, dev)
         self._vit_rope_cache = {}
         self._vis_stream = None            # side stream the NEXT chunk's ViT runs on while this chunk decodes
-        self._vis_pending = None           # (pixel tensor, grid, event, features)
+        self._vis_pending = None           # [pixel tensor, grid, event, features, unfinished _VitRun]
+        # ViT blocks of a look-ahead pass held back for the gap between chunks (~0.19 ms each at 448x448 on the 2B tower)
+        self.vit_tail = int(os.environ.get("SVLM_VIT_TAIL", 5))
         self._graph = None
         self._graph_key = None
         self._penalty = 1.0
@@ -121,72 +176,72 @@ class SvlmEngine:
 
     def vision_forward(self, pixel_values, grid_thw):
         """streaming_visual_encoder_forward: (N, C*T*P*P) patches -> (N / merge^2, hidden)."""
-        o, w, vc = self.ops, self.w, self.cfg.vision
-        grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
-        N = sum(t * h * ww for t, h, ww in grid)
-        if pixel_values.shape[0] != N or pixel_values.shape[1] != vc.patch_dim:
-            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {grid} (N={N}, patch_dim={vc.patch_dim})")
-        sizes = {h * ww for _, h, ww in grid}
-        if len(sizes) != 1:
-            raise ValueError("all temporal grids of one call must share h*w")
-        seq_len = sizes.pop()
-        n_seq = N // seq_len
-        pix = pixel_values.to(device=self.device, dtype=BF16).contiguous()
-        cosT, sinT = self._vit_rope(grid)
-        E, Hh, d = vc.embed_dim, vc.num_heads, vc.head_dim
-        x = o.gemm(pix, w.patch_embed)
-        h = torch.empty_like(x)
-        qkv = torch.empty((N, 3 * E), dtype=BF16, device=self.device)
-        a = torch.empty((N, E), dtype=BF16, device=self.device)
-        f = torch.empty((N, vc.mlp_hidden), dtype=BF16, device=self.device)
-        scale = 1.0 / math.sqrt(d)
-        for bw in w.vit:
-            o.layernorm(x, bw["n1w"], bw["n1b"], 1e-6, out=h)
-            o.gemm(h, bw["qkv_w"], bias=bw["qkv_b"], out=qkv)
-            o.vit_rope(qkv, cosT, sinT, Hh, d)
-            o.vit_attn(qkv, n_seq, seq_len, Hh, d, scale, out=a)
-            o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
-            o.layernorm(x, bw["n2w"], bw["n2b"], 1e-6, out=h)
-            o.gemm(h, bw["fc1_w"], bias=bw["fc1_b"], out=f, act=ACT_QUICK_GELU)
-            o.gemm(f, bw["fc2_w"], bias=bw["fc2_b"], residual=x, out=x)
-        mg = w.merger
-        o.layernorm(x, mg["ln_w"], mg["ln_b"], 1e-6, out=h)
-        m2 = vc.spatial_merge_size ** 2
-        hm = h.view(N // m2, E * m2)
-        g1 = o.gemm(hm, mg["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
-        return o.gemm(g1, mg["w2"], bias=mg["b2"])
+        run = _VitRun(self, pixel_values, grid_thw)
+        run.blocks(0, self.cfg.vision.depth)
+        return run.finish()
 
     def vision_prefetch(self, pixel_values, grid_thw):
-        """Enqueue the ViT + merger of the NEXT chunk's frames on a side stream.  Frames do not depend on generated text,
-        so their encoding overlaps this chunk's decode steps (HBM/latency-bound GEMVs that leave the MFMA pipes idle).
-        The side stream starts after everything already enqueued on the current stream (this chunk's prefill: the two
-        never run GEMMs at the same time, so the split-K scratch is not shared) and `generate` of the next chunk waits
-        on the recorded event when it is handed the SAME pixel tensor."""
+        """Enqueue the ViT + merger of the NEXT chunk's frames.  Frames do not depend on generated text, so most of the
+        pass runs on a side stream underneath this chunk's decode steps (HBM/latency-bound GEMVs that leave the MFMA
+        pipes idle).  The side stream starts after everything already enqueued on the current stream (this chunk's
+        prefill: the two never run GEMMs at the same time, so the split-K scratch is not shared).  The last `vit_tail`
+        blocks and the merger are held back for `vision_prefetch_finish`, which puts them on the MAIN stream behind the
+        last decode step: they run during the host's turnaround between chunks, when the GPU would otherwise idle.
+        `generate` of the next chunk picks the features up when it is handed the SAME pixel tensor."""
         if self.device.type != "cuda":
             return
+        self._vision_drain()
         if self._vis_stream is None:
             # (stream priorities were measured and make no difference here: the device offers only normal/high and the
             # decode workgroups are not dispatch-starved, they share HBM and CUs with the ViT tiles)
             self._vis_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
         self._vis_stream.wait_stream(main)
+        depth = self.cfg.vision.depth
+        tail = min(max(self.vit_tail, 0), depth)
         with torch.cuda.stream(self._vis_stream):
-            out = self.vision_forward(pixel_values, grid_thw)
+            run = _VitRun(self, pixel_values, grid_thw)
+            run.blocks(0, depth - tail)
+            out = run.finish() if self.vit_tail < 0 else None          # < 0: nothing held back
             ev = torch.cuda.Event()
             ev.record(self._vis_stream)
         grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
-        self._vis_pending = (pixel_values, grid, ev, out)
+        self._vis_pending = [pixel_values, grid, ev, out, run if out is None else None]
+
+    def vision_prefetch_finish(self):
+        """Held-back tail of a look-ahead pass, on the CURRENT stream; call once the chunk's decode steps are enqueued."""
+        pend = self._vis_pending
+        if pend is None or pend[4] is None:
+            return
+        run, pend[4] = pend[4], None
+        main = torch.cuda.current_stream()
+        main.wait_event(pend[2])                       # the side stream's blocks: long finished by now
+        for t in (run.x, run.h, run.qkv, run.a, run.f):
+            t.record_stream(main)                      # allocated on the side stream, used here
+        depth = self.cfg.vision.depth
+        run.blocks(depth - min(self.vit_tail, depth), depth)
+        pend[3] = run.finish()
+        pend[2] = None
+
+    def _vision_drain(self):
+        """Drop a look-ahead nobody consumed (the caller changed its mind): let the side stream finish first."""
+        pend, self._vis_pending = self._vis_pending, None
+        if pend is not None:
+            self._vis_stream.synchronize()
 
     def _vision(self, pixel_values, grid_thw):
-        pend, self._vis_pending = self._vis_pending, None
+        pend = self._vis_pending
         if pend is not None:
             grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
             if pend[0] is pixel_values and pend[1] == grid:
-                main = torch.cuda.current_stream()
-                main.wait_event(pend[2])
-                pend[3].record_stream(main)
+                self.vision_prefetch_finish()          # no-op when generate() already issued the tail
+                self._vis_pending = None
+                if pend[2] is not None:                # whole pass ran on the side stream
+                    main = torch.cuda.current_stream()
+                    main.wait_event(pend[2])
+                    pend[3].record_stream(main)
                 return pend[3]
-            pend[2].synchronize()          # stale look-ahead (caller changed its mind): let it drain, then recompute
+            self._vision_drain()
         return self.vision_forward(pixel_values, grid_thw)
 
     # ------------------------------------------------------------------ LLM
@@ -334,7 +389,16 @@ class SvlmEngine:
             self._decode_step(cache)
             if keep_logits:
                 logits_out.append(self.logits.detach().cpu().clone())
-        toks = self.tok_buf[:max_new_tokens].cpu().numpy()               # the one host sync of the chunk
+        # the one host sync of the chunk waits for the TOKENS only: the held-back ViT tail of the look-ahead pass is enqueued
+        # behind the copy and keeps the GPU busy while the host turns the chunk around
+        if self.device.type == "cuda":
+            self._tok_host[:max_new_tokens].copy_(self.tok_buf[:max_new_tokens], non_blocking=True)
+            self._tok_ev.record()
+            self.vision_prefetch_finish()
+            self._tok_ev.synchronize()
+            toks = self._tok_host[:max_new_tokens].numpy().copy()
+        else:                                                            # host-side test backend
+            toks = self.tok_buf[:max_new_tokens].numpy().copy()
         n_new = max_new_tokens
         for j, t in enumerate(toks):
             if int(t) in cfg.eos_token_ids:
