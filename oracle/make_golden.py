@@ -179,8 +179,10 @@ def gen_oracle_vectors():
         "structural_t3_v2": dict(policy="structural", text_round=3, window_size=2, text_sink=2, text_sliding_window=6,
                                  previous_text="a b c d e f g h i j k l m n o p"),
         "structural_default_16": dict(policy="structural", text_round=16, window_size=16, text_sink=512, text_sliding_window=512),
+        # BASELINE configs[0] geometry: 32 frames of 224x224 (64 vision tokens each), sink 4 / window 256, greedy, rep-pen 1.05
+        "cfg0_224_sink4_win256_32": dict(policy="sink_window", sink=4, window=256, size=224),
     }.items():
-        n = 20 if "default" in name else 10
+        n = 20 if "default" in name else (32 if name.startswith("cfg0") else 10)
         o = H.run_oracle_stream(cfg, sd, n, **kw)
         runs[name] = {"kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"]}
     with open(os.path.join(OUT, "oracle_streams.json"), "w") as f:

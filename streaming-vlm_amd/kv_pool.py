@@ -18,6 +18,28 @@ import numpy as np
 import torch
 
 
+class _LayerPlanes:
+    """`past_key_values.key_cache` / `.value_cache` of the reference's cache object (a list of per-layer
+    (1, Hkv, L, D) tensors, generate/streaming_cache.py:6-28): reads gather the layer in logical order, assignment
+    (inference.py:58-59 writes the pruned tensors back this way) stores the rows through the slot table."""
+
+    def __init__(self, pool: "KVPool", which: int):
+        self._pool, self._which = pool, which
+
+    def __len__(self):
+        return self._pool.n_layers
+
+    def __getitem__(self, layer: int):
+        return self._pool.layer_kv(layer)[self._which]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __setitem__(self, layer: int, rows):
+        self._pool._assign_plane(layer, self._which, rows)
+
+
 class KVPool:
     def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_len: int, device, ops, page_tokens: int = 16,
                  slack: float = 1.0):
@@ -41,6 +63,9 @@ class KVPool:
         self.open_fill = page_tokens
         self._dirty_from = 0
         self.stats = dict(moved_rows=0, defrags=0, evicted_rows=0)
+        self.key_cache, self.value_cache = _LayerPlanes(self, 0), _LayerPlanes(self, 1)
+        self._half = {}           # layer -> (which, rows): one plane assigned, waiting for its partner
+        self._upd_rows = 0        # rows of an update() pass that has not reached the last layer yet
 
     # ------------------------------------------------------------------ allocation
     def _take_slot(self) -> int:
@@ -176,8 +201,67 @@ class KVPool:
     def get_seq_length(self) -> int:
         return self.length
 
+    def _rows2d(self, t):
+        """(1, Hkv, n, D) or (Hkv, n, D) -> (n, Hkv*D) bf16 rows on the pool's device."""
+        t = t.reshape(self.Hkv, -1, self.D) if t.dim() == 4 else t
+        if t.dim() != 3 or t.shape[0] != self.Hkv or t.shape[2] != self.D:
+            raise ValueError(f"expected (1, {self.Hkv}, L, {self.D}) rows, got {tuple(t.shape)}")
+        return t.to(device=self.device, dtype=torch.bfloat16).permute(1, 0, 2).reshape(t.shape[1], self.Hkv * self.D).contiguous()
+
+    def _assign_plane(self, layer: int, which: int, rows):
+        """`cache.key_cache[i] = k` / `cache.value_cache[i] = v`: a layer's K and V are written together once both
+        halves are there (svlm_kv_append stores a K row and a V row per slot).  The first assignment whose length
+        differs from the cache's re-sizes the logical sequence (drops or adds TAIL rows): the reference always
+        rewrites every layer in full, so which physical rows survive is immaterial."""
+        if not 0 <= layer < self.n_layers:
+            raise IndexError(layer)
+        r = self._rows2d(rows)
+        other = self._half.pop(layer, None)
+        if other is None:
+            self._half[layer] = (which, r)
+            return
+        if other[0] == which or other[1].shape[0] != r.shape[0]:
+            raise ValueError(f"layer {layer}: key_cache[i] and value_cache[i] must be assigned as a pair of equal length")
+        k, v = (other[1], r) if which == 1 else (r, other[1])
+        n = k.shape[0]
+        if n != self.length:
+            self.release_reserved()
+            if n < self.length:
+                self.truncate(n)
+            else:
+                self.reserve(n - self.length)
+                self.commit(n)
+        if n:
+            self.sync_device()
+            self.ops.kv_append(k, v, self.pool, layer, self.slot_of_dev, 0, n)
+
+    def update(self, key_states, value_states, layer_idx: int, cache_kwargs=None):
+        """`StreamingCache.update` (generate/streaming_cache.py:30-74): append T new rows to layer `layer_idx` and
+        return that layer's full (1, Hkv, L + T, D) K and V.  Slots are taken when layer 0 arrives, the logical
+        length grows when the last layer has been written."""
+        k, v = self._rows2d(key_states), self._rows2d(value_states)
+        T = k.shape[0]
+        if layer_idx == 0:
+            if self._upd_rows:
+                raise RuntimeError("update(): the previous pass did not reach the last layer")
+            self.release_reserved()
+            self.reserve(T)
+            self.sync_device()
+            self._upd_rows = T
+        if T != self._upd_rows or v.shape[0] != T:
+            raise ValueError(f"update(): layer {layer_idx} brings {T} rows, layer 0 brought {self._upd_rows}")
+        self.ops.kv_append(k, v, self.pool, layer_idx, self.slot_of_dev, self.length, T)
+        n = self.length + T
+        out = tuple(self.ops.kv_gather(self.pool, layer_idx, w, self.slot_of_dev, n).unsqueeze(0) for w in (0, 1))
+        if layer_idx == self.n_layers - 1:
+            self.commit(n)
+            self._upd_rows = 0
+        return out
+
     def layer_kv(self, layer: int):
         """Dense (1, Hkv, L, D) K and V in logical order, like the tensors the reference's cache holds."""
+        if self._half:
+            raise RuntimeError(f"layers {sorted(self._half)}: only one of key_cache[i] / value_cache[i] has been assigned")
         self.sync_device()
         k = self.ops.kv_gather(self.pool, layer, 0, self.slot_of_dev, self.length)
         v = self.ops.kv_gather(self.pool, layer, 1, self.slot_of_dev, self.length)

@@ -112,6 +112,27 @@ def test_graph_replay_equals_eager_launches():
             assert torch.equal(x, y)
 
 
+def test_golden_streams_eviction_trace_and_tokens():
+    """Committed oracle streams (tests/golden/oracle_streams.json, minted by oracle/make_golden.py) replayed on the HIP
+    engine with no oracle in the loop: eviction indices and KV lengths must be identical; greedy tokens are compared
+    chunk by chunk up to the first bf16-noise flip (histories differ from there on)."""
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_streams.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        cfg, sd, model = _tiny_model()
+        _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], **dict(g["kwargs"]))
+        assert [[list(t) for t in c] for c in trace] == g["trace"], name
+        assert [e["kv_len"] for e in ids_log] == g["kv_len"], name
+        same = 0
+        for e, want in zip(ids_log, g["new_tokens"]):
+            if e["new"] != want:
+                break
+            same += 1
+        print(f"[golden] {name}: {same}/{g['n_chunks']} chunks token-identical before the first flip")
+        assert same >= 1, name
+
+
 def test_vision_lookahead_is_bitwise_neutral():
     """Encoding chunk i+1's frames on the side stream under chunk i's decode steps must not change a single bit."""
     outs = []

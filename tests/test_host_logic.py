@@ -124,6 +124,51 @@ def _rows(pool, layer=0):
     return pool_k[0, 0, :, 0].float().tolist(), pool_v[0, 1, :, 5].float().tolist()
 
 
+def test_cache_object_contract_of_the_reference():
+    """SURVEY 8b "Cache object": iteration yields (k, v) with shape[2] == L, key_cache[i] / value_cache[i] are readable
+    and ASSIGNABLE (the reference's prune writes index_select results back, inference.py:54-59), get_seq_length(),
+    update(k, v, layer_idx, cache_kwargs) appends and returns the full layer (streaming_cache.py:30-74)."""
+    pool = _pool()
+    pool.slot_of_dev = torch.from_numpy(pool.slot_of)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda n: torch.randn(1, 2, n, 128, generator=g).to(torch.bfloat16)
+    # update(): two chunks, every layer; the returned tensors are the full layer in logical order
+    ref = [[None, None] for _ in range(2)]
+    for T in (37, 5):
+        for layer in range(2):
+            k, v = mk(T), mk(T)
+            ref[layer][0] = k if ref[layer][0] is None else torch.cat([ref[layer][0], k], 2)
+            ref[layer][1] = v if ref[layer][1] is None else torch.cat([ref[layer][1], v], 2)
+            ko, vo = pool.update(k, v, layer, None)
+            assert torch.equal(ko, ref[layer][0]) and torch.equal(vo, ref[layer][1])
+    assert pool.get_seq_length() == 42 and len(pool) == 2 and len(pool.key_cache) == 2
+    for layer, (k, v) in enumerate(pool):
+        assert k.shape == (1, 2, 42, 128) and torch.equal(k, ref[layer][0]) and torch.equal(v, ref[layer][1])
+        assert torch.equal(pool.key_cache[layer], k) and torch.equal(pool.value_cache[layer], v)
+    # the reference's prune, verbatim in shape: index_select on dim 2, assign back per layer
+    keep = torch.tensor([i for i in range(42) if not 4 <= i <= 20])
+    for i, (k, v) in enumerate(list(pool)):
+        pool.key_cache[i] = torch.index_select(k, 2, keep)
+        pool.value_cache[i] = torch.index_select(v, 2, keep)
+    assert pool.get_seq_length() == 25
+    for layer, (k, v) in enumerate(pool):
+        assert torch.equal(k, ref[layer][0][:, :, keep]) and torch.equal(v, ref[layer][1][:, :, keep])
+    # ... and it agrees with the in-place edit the product uses instead
+    other = _pool()
+    other.slot_of_dev = torch.from_numpy(other.slot_of)
+    for layer in range(2):
+        other.update(ref[layer][0], ref[layer][1], layer)
+    other.prune(4, 20)
+    for (k0, v0), (k1, v1) in zip(pool, other):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1)
+    # half-assigned layers are an error at the next read, not silent garbage
+    pool.key_cache[0] = mk(25)
+    with pytest.raises(RuntimeError):
+        pool.layer_kv(0)
+    with pytest.raises(ValueError):
+        pool.value_cache[0] = mk(24)
+
+
 def test_pool_prune_move_truncate_match_list_semantics():
     pool = _pool()
     pool.slot_of_dev = torch.from_numpy(pool.slot_of)      # CPU "device" mirror shares memory

@@ -262,6 +262,32 @@ def test_prefill_matches_decode_on_last_row(ops):
     close("prefill last row vs decode", out[T - 1], o1, max_tol=2 ** -6, mean_tol=1e-3)
 
 
+def test_kvpool_reference_cache_contract_on_device(ops):
+    """update() / key_cache[i] = ... / iteration of the reference's cache object, through svlm_kv_append / svlm_kv_gather."""
+    import streaming_vlm_amd as S
+    pool = S.KVPool(3, 2, 128, 256, "cuda", ops, page_tokens=16, slack=0.25)
+    ref = [[None, None] for _ in range(3)]
+    for j, T in enumerate((50, 1, 7)):
+        for layer in range(3):
+            k, v = rnd((1, 2, T, 128), 40 + 10 * j + layer).cuda(), rnd((1, 2, T, 128), 80 + 10 * j + layer).cuda()
+            ref[layer][0] = k if ref[layer][0] is None else torch.cat([ref[layer][0], k], 2)
+            ref[layer][1] = v if ref[layer][1] is None else torch.cat([ref[layer][1], v], 2)
+            ko, vo = pool.update(k, v, layer, None)
+            assert torch.equal(ko, ref[layer][0]) and torch.equal(vo, ref[layer][1])
+    keep = torch.tensor([i for i in range(58) if not 4 <= i <= 30], device="cuda")
+    for i, (k, v) in enumerate(list(pool)):
+        pool.key_cache[i] = torch.index_select(k, 2, keep)
+        pool.value_cache[i] = torch.index_select(v, 2, keep)
+    assert pool.get_seq_length() == 31
+    other = S.KVPool(3, 2, 128, 256, "cuda", ops, page_tokens=16, slack=0.25)
+    for layer in range(3):
+        other.update(ref[layer][0], ref[layer][1], layer)
+    other.prune(4, 30)
+    for layer, ((k0, v0), (k1, v1)) in enumerate(zip(pool, other)):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1)
+        assert torch.equal(k0, ref[layer][0][:, :, keep]) and torch.equal(v0, ref[layer][1][:, :, keep])
+
+
 # ----------------------------------------------------------------------------- sampling
 def test_penalty_argmax(ops, ref):
     V = 151936
