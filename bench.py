@@ -73,7 +73,8 @@ def main():
     sd = random_state_dict(cfg, 0, dev)
     model = S.StreamingQwen2VL(cfg, sd, dev, max_len=max_len, max_new_tokens=args.new_tokens)
     log("engine ready; staging the synthetic stream in HBM")
-    video = ResidentVideo(n_chunks + 1, args.size, args.fps, rank, dev)          # inputs resident in HBM before timing
+    # inputs resident in HBM before timing; long runs cycle through 128 distinct chunks
+    video = ResidentVideo(n_chunks + 1, args.size, args.fps, rank, dev, period=128 if n_chunks > 256 else 0)
     proc = ResidentProcessor()
     frames_per_chunk = video.frames_per_chunk
 
@@ -85,7 +86,10 @@ def main():
     def fence():
         MS.fence(dist, dev)
 
+    stamps = []
+
     def on_chunk(i):
+        stamps.append(time.perf_counter())
         if i == 0:
             log("stream started (warmup)")
         if i == args.warmup:
@@ -99,6 +103,9 @@ def main():
                           ids_log=kvlog)
     fence()
     kv_steady[0] = kvlog[-1]["kv_len"]
+    kv_max = max(e["kv_len"] for e in kvlog)
+    pool = getattr(model._svlm_engine, "_last_cache", None)
+    cache_stats = dict(kv_len_max=kv_max, **(pool.stats if pool is not None else {}))
     elapsed = time.perf_counter() - t["t0"]
     log(f"timed region done: {elapsed:.3f} s for {args.steps} chunks")
     frames = args.steps * frames_per_chunk
@@ -116,7 +123,13 @@ def main():
                    "frames_per_chunk": frames_per_chunk, "new_tokens_per_chunk": args.new_tokens, "kv_len_steady": kv_steady[0],
                    "parallelism": f"streams{world}"},
         "per_gpu_frames_per_sec": [round(v, 3) for v in per_gpu_fps],
+        # wall time of a chunk per generated token, the figure eval/efficiency/efficiency_test.py:87-99 reports
+        "chunk_ms_per_token": round(1e3 * t_max / max(1, tokens), 4),
+        "kv_pool": {k: int(v) for k, v in cache_stats.items()},
     }
+    if args.steps >= 400:      # drift over a long stream: mean chunk time of the first / last 100 timed chunks
+        d = [1e3 * (b - a) for a, b in zip(stamps[args.warmup:-1], stamps[args.warmup + 1:])]
+        out["ms_per_step_first100"], out["ms_per_step_last100"] = round(sum(d[:100]) / 100, 3), round(sum(d[-100:]) / 100, 3)
 
     if rank == 0 and not args.no_roofline:
         log("roofline pass (eager launches bracketed by HIP events)")

@@ -331,6 +331,7 @@ class SvlmEngine:
         if cache is None:
             cache = self.new_cache()
         cache.release_reserved()
+        self._last_cache = cache
         L_before, L_ids = cache.length, int(ids.shape[0])
         T = L_ids - L_before
         if T < 1:

@@ -50,7 +50,13 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     if input_ids.shape[0] != 1:
         raise ValueError("the streaming loop is batch-1")
     ids = input_ids[0].tolist()
-    grids_all = _grid_list(streaming_args.video_grid_thw if streaming_args.video_grid_thw is not None else video_grid_thw)
+    # The reference never prunes streaming_args.video_grid_thw (one more row per chunk, inference.py:415) and indexes it
+    # from row 0 in order of appearance of the surviving vision spans (qwen2/pos_emb.py:85-108).  Same rows here, but only
+    # as many as there are spans: the conversion stays O(window) on an hour-long stream instead of O(chunks so far).
+    g_all = streaming_args.video_grid_thw if streaming_args.video_grid_thw is not None else video_grid_thw
+    if g_all is not None and len(g_all) > 64:
+        g_all = g_all[:ids.count(eng.cfg.vision_start_token_id)]
+    grids_all = _grid_list(g_all)
     out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
                        repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision)
     # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)

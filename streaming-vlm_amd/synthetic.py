@@ -188,17 +188,19 @@ class ResidentVideo:
     region starts with its inputs in HBM (bench.py)."""
 
     def __init__(self, n_chunks: int, size: int, fps: float, stream: int, device, chunk_duration: float = 1.0,
-                 patch: int = 14, temporal: int = 2, merge: int = 2):
+                 patch: int = 14, temporal: int = 2, merge: int = 2, period: int = 0):
+        """`period` > 0 keeps only that many distinct chunks resident and cycles through them (hour-long streams:
+        3600 chunks of 448x448 would otherwise hold 8.7 GB of patches and minutes of host patchify)."""
         src = SyntheticVideo(size, fps, stream)
         self.chunk_duration = chunk_duration
         self.frames_per_chunk = max(1, int(round(chunk_duration * fps)))
         self.chunks = []
-        for i in range(n_chunks):
+        for i in range(min(n_chunks, period) if period > 0 else n_chunks):
             pix, grid = patchify(src.chunk(i * chunk_duration, chunk_duration), patch, temporal, merge)
             self.chunks.append(ResidentChunk(pix.to(device), grid))
 
     def chunk(self, start_s: float, duration_s: float) -> ResidentChunk:
-        return self.chunks[int(round(start_s / self.chunk_duration))]
+        return self.chunks[int(round(start_s / self.chunk_duration)) % len(self.chunks)]
 
 
 class ResidentProcessor(SyntheticProcessor):
