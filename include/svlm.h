@@ -73,6 +73,13 @@ int svlm_silu_mul(const void* gu, void* h, int rows, int inter, void* stream);
 int svlm_gather_rows(const void* table, const void* alt, const int* idx, const int* idx_off, void* out, int rows, int cols,
                      void* stream);
 
+/* Frame ingest: uint8 frames (T,3,H,W) -> bf16 patches (ceil(T/temporal)*(H/patch)*(W/patch), 3*temporal*patch*patch),
+ * rescaled by 1/255, normalised per channel, rows in merge-block-major order, a trailing odd frame repeated.
+ * replaces: the HF video processor's rescale/normalize/patchify on the host (called at inference.py:390-395;
+ * $TF/models/qwen2_vl/video_processing_qwen2_vl.py:247-270) -- SURVEY 8f-2. */
+int svlm_patchify_u8(const void* frames, void* out, int T, int H, int W, int patch, int temporal, int merge,
+                     float m0, float m1, float m2, float s0, float s1, float s2, void* stream);
+
 /* In-place 2-D rope on the q and k parts of the fused ViT qkv buffer (N,3,H,d); cosT/sinT fp32 (N,d/2).
  * replaces: apply_rotary_pos_emb_vision (qwen2/vision_forward.py:27). */
 int svlm_vit_rope(void* qkv, const float* cosT, const float* sinT, int N, int H, int d, void* stream);

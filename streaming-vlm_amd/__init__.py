@@ -16,7 +16,8 @@ from .engine import SvlmEngine  # noqa: F401
 from .model import StreamingArgs, StreamingQwen2VL, convert_qwen2_to_streaming, streaming_generate  # noqa: F401
 from .driver import (contiguous_id_and_kv, load_model_and_processor, open_vtt, process_past_kv, prune_id_and_kv_cache,  # noqa: F401
                      resort_id_and_kv, sec2ts, sink_window_evict, streaming_inference)
-from .synthetic import SyntheticProcessor, SyntheticVideo, patchify, synthetic_frame  # noqa: F401
+from .synthetic import (DeviceFrameProcessor, PinnedVideo, SyntheticProcessor, SyntheticVideo, patchify,  # noqa: F401
+                        synthetic_frame)
 from .weights import random_state_dict  # noqa: F401
 
 __version__ = "0.1.0"

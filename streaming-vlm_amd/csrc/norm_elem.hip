@@ -227,3 +227,40 @@ extern "C" int svlm_prefetch(const void* ptr, long long bytes, int n_wgs, void* 
   prefetch_kernel<<<n_wgs, 256, 0, (hipStream_t)stream>>>((const u32x4_t*)ptr, bytes / 16);
   return svlm_check_launch("svlm_prefetch");
 }
+
+// ---------------------------------------------------------------- frame ingest
+// uint8 frames (T, 3, H, W) -> bf16 patches (gt*gh*gw, 3*TP*P*P): rescale 1/255, per-channel normalise and the
+// merge-block-major patch order of the Qwen2-VL video processor (the 2x2 patches that the merger fuses are consecutive
+// rows); a trailing odd frame is repeated to fill its temporal patch.  One workgroup per output row.
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ frames, bf16_t* __restrict__ out,
+                                                          int T, int H, int W, int P, int TP, int MG, float m0, float m1, float m2,
+                                                          float s0, float s1, float s2) {
+  const int gh = H / P, gw = W / P;
+  const int row = blockIdx.x;
+  // row = ((t * gh/MG + hb) * gw/MG + wb) * MG*MG + mh*MG + mw
+  const int mm = row % (MG * MG), blk = row / (MG * MG);
+  const int wb = blk % (gw / MG), hb = (blk / (gw / MG)) % (gh / MG), t = blk / ((gw / MG) * (gh / MG));
+  const int ph0 = (hb * MG + mm / MG) * P, pw0 = (wb * MG + mm % MG) * P;
+  const int cols = 3 * TP * P * P;
+  for (int col = threadIdx.x; col < cols; col += 256) {
+    const int pw = col % P, ph = (col / P) % P, tt = (col / (P * P)) % TP, c = col / (P * P * TP);
+    const int f = min(t * TP + tt, T - 1);
+    const float x = (float)frames[(((size_t)f * 3 + c) * H + ph0 + ph) * W + pw0 + pw] / 255.0f;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    out[(size_t)row * cols + col] = f2bf((x - mean) / sd);
+  }
+}
+
+extern "C" int svlm_patchify_u8(const void* frames, void* out, int T, int H, int W, int patch, int temporal, int merge,
+                                float m0, float m1, float m2, float s0, float s1, float s2, void* stream) {
+  SVLM_CHECK_ARG(T > 0 && patch > 0 && temporal > 0 && merge > 0, "svlm_patchify_u8: bad T=%d patch=%d temporal=%d merge=%d", T, patch, temporal, merge);
+  SVLM_CHECK_ARG(H > 0 && W > 0 && H % (patch * merge) == 0 && W % (patch * merge) == 0,
+                 "svlm_patchify_u8: frame %dx%d is not a multiple of %d", H, W, patch * merge);
+  SVLM_CHECK_ARG(s0 != 0.f && s1 != 0.f && s2 != 0.f, "svlm_patchify_u8: zero std");
+  const int gt = (T + temporal - 1) / temporal;
+  const long long rows = (long long)gt * (H / patch) * (W / patch);
+  SVLM_CHECK_ARG(rows < (1LL << 31), "svlm_patchify_u8: too many patches");
+  patchify_u8_kernel<<<(int)rows, 256, 0, (hipStream_t)stream>>>((const unsigned char*)frames, (bf16_t*)out, T, H, W, patch, temporal, merge,
+                                                                 m0, m1, m2, s0, s1, s2);
+  return svlm_check_launch("svlm_patchify_u8");
+}

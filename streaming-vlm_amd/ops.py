@@ -162,6 +162,23 @@ class HipOps:
               "svlm_gather_rows")
         return out
 
+    def patchify_u8(self, frames, patch=14, temporal=2, merge=2, mean=(0.48145466, 0.4578275, 0.40821073),
+                    std=(0.26862954, 0.26130258, 0.27577711), out=None):
+        """uint8 (T, 3, H, W) frames on the device -> (bf16 patches (N, 3*temporal*patch^2), [[gt, gh, gw]])."""
+        _req(frames, torch.uint8, "patchify.frames", 4)
+        T, C, H, W = frames.shape
+        assert C == 3 and frames.is_contiguous()
+        gt, gh, gw = (T + temporal - 1) // temporal, H // patch, W // patch
+        cols = 3 * temporal * patch * patch
+        if out is None:
+            out = torch.empty((gt * gh * gw, cols), dtype=BF16, device=frames.device)
+        _req(out, BF16, "patchify.out", 2)
+        assert out.is_contiguous() and tuple(out.shape) == (gt * gh * gw, cols)
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))          # the exact fp32 constants torch.tensor(list) holds
+        check(self.lib.svlm_patchify_u8(_ptr(frames), _ptr(out), T, H, W, patch, temporal, merge, f32(mean[0]), f32(mean[1]), f32(mean[2]),
+                                        f32(std[0]), f32(std[1]), f32(std[2]), _stream()), "svlm_patchify_u8")
+        return out, [[gt, gh, gw]]
+
     # ------------------------------------------------------------------ ViT
     def vit_rope(self, qkv, cosT, sinT, H, d):
         _req(qkv, BF16, "vit_rope.qkv", 2); _req(cosT, torch.float32, "vit_rope.cos", 2); _req(sinT, torch.float32, "vit_rope.sin", 2)

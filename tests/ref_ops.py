@@ -80,6 +80,15 @@ class RefOps:
         out.copy_(y)
         return out
 
+    def patchify_u8(self, frames, patch=14, temporal=2, merge=2, out=None):
+        from streaming_vlm_amd.synthetic import patchify
+        pix, grid = patchify(frames, patch, temporal, merge)
+        pix = pix.to(torch.bfloat16)
+        if out is not None:
+            out.copy_(pix)
+            pix = out
+        return pix, grid
+
     def gather_rows(self, table, alt, idx, out, idx_off=None):
         off = int(idx_off[0]) if idx_off is not None else 0
         rows = out.shape[0]

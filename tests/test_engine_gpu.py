@@ -147,6 +147,25 @@ def test_vision_lookahead_is_bitwise_neutral():
             assert torch.equal(x, y)
 
 
+def test_device_frame_ingest_equals_host_processor():
+    """uint8 frames -> H2D -> svlm_patchify_u8 gives the same stream, bit for bit, as host patchify + upload."""
+    import streaming_vlm_amd as S
+    outs = []
+    for dev_ingest in (False, True):
+        cfg, sd, model = _tiny_model()
+        proc = S.DeviceFrameProcessor(model._svlm_engine.ops) if dev_ingest else S.SyntheticProcessor()
+        video = S.PinnedVideo(5, 56, 1.0, 0) if dev_ingest else None
+        ids_log = []
+        S.streaming_inference(model=model, processor=proc, video=video, video_path="synthetic://56x56@1fps", model_base="Qwen2",
+                              duration=5, previous_text="hello world", kv_policy="sink_window", sink=4, window=64, do_sample=False,
+                              max_new_tokens=8, suppress_eos=True, quiet=True, ids_log=ids_log, keep_logits=True)
+        outs.append(ids_log)
+    for a, b in zip(*outs):
+        assert a["ids"] == b["ids"]
+        for x, y in zip(a["logits"], b["logits"]):
+            assert torch.equal(x, y)
+
+
 def test_eos_truncates_and_rolls_back_kv():
     import streaming_vlm_amd as S
     cfg, sd, model = _tiny_model()

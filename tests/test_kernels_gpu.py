@@ -288,6 +288,21 @@ def test_kvpool_reference_cache_contract_on_device(ops):
         assert torch.equal(k0, ref[layer][0][:, :, keep]) and torch.equal(v0, ref[layer][1][:, :, keep])
 
 
+@pytest.mark.parametrize("T,H,W", [(1, 448, 448), (2, 448, 448), (3, 56, 84), (1, 224, 224), (4, 28, 28)])
+def test_patchify_u8_bit_exact(ops, T, H, W):
+    """GPU frame ingest == the host processor's rescale / normalise / merge-block-major patchify, bit for bit in bf16
+    (odd T: the last frame is repeated to fill its temporal patch)."""
+    from streaming_vlm_amd.synthetic import patchify
+    g = torch.Generator().manual_seed(T * 1000 + H + W)
+    frames = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
+    want, grid_w = patchify(frames)
+    got, grid = ops.patchify_u8(frames.cuda())
+    assert grid == grid_w and got.shape == want.shape
+    assert torch.equal(got.cpu(), want.to(BF16))
+    with pytest.raises(Exception):
+        ops.patchify_u8(torch.zeros((1, 3, 30, 28), dtype=torch.uint8, device="cuda"))
+
+
 # ----------------------------------------------------------------------------- sampling
 def test_penalty_argmax(ops, ref):
     V = 151936
