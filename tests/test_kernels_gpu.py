@@ -93,6 +93,8 @@ def test_gemm_rejects_bad_shapes(ops):
     (2048, 1536, True, False, False), (1536, 1536, False, True, False), (17920, 1536, False, False, False),
     (1536, 8960, False, True, False), (151936, 1536, False, False, True), (520, 264, True, True, False), (7, 8, False, False, True),
     (3584, 18944, False, True, False), (100, 4104, True, False, False),
+    # K-split path with a ragged last batch and odd N, a second batch per wave (K > 4 x 5 x 512), main path with K % 512 != 0
+    (1535, 4104, True, True, False), (64, 12288, False, True, True), (4100, 1176, True, False, False), (16500, 520, False, True, False),
 ])
 def test_gemv(ops, ref, N, K, bias, res, f32):
     x, W = rnd((K,), 1), rnd((N, K), 2, 0.05)
@@ -336,7 +338,9 @@ def test_penalty_argmax(ops, ref):
 
 
 # ----------------------------------------------------------------------------- fused decode-step kernels
-@pytest.mark.parametrize("H,Hq,Hkv,I,V", [(1536, 12, 2, 8960, 151936), (3584, 28, 4, 18944, 152064), (256, 4, 2, 512, 151680)])
+# hidden sizes pick the (pre-issued K-steps, x chunks per thread) variant: <=1536 (3,1), <=2048 (4,1), <=4096 (4,2), else (4,4)
+@pytest.mark.parametrize("H,Hq,Hkv,I,V", [(1536, 12, 2, 8960, 151936), (3584, 28, 4, 18944, 152064), (256, 4, 2, 512, 151680),
+                                          (2048, 16, 2, 1000, 5000), (8192, 8, 8, 520, 3001), (1544, 4, 2, 36, 130)])
 def test_fused_decode_kernels(ops, ref, H, Hq, Hkv, I, V):
     D = 128
     qd, kd = Hq * D, Hkv * D
@@ -363,7 +367,7 @@ def test_fused_decode_kernels(ops, ref, H, Hq, Hkv, I, V):
     Wl = rnd((V, H), 8, 0.03)
     g = torch.Generator().manual_seed(9)
     ids = torch.randint(0, V, (300,), generator=g, dtype=torch.int32)
-    sup = torch.tensor([151645, 151643], dtype=torch.int32)
+    sup = torch.tensor([151645, 151643] if V > 151645 else [V - 7, V - 3], dtype=torch.int32)
     lg_c, lg_g = torch.zeros(V), torch.zeros(V, device="cuda")
     seen_c = torch.zeros(V, dtype=torch.uint8)
     ref.mark_seen(ids, 300, seen_c)
