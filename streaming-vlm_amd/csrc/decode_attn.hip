@@ -17,6 +17,7 @@
 // the four waves merge through LDS; a second small kernel merges the splits with the splits
 // spread over waves and the loads unrolled.
 #include "common.h"
+#include <stdlib.h>
 
 #define DA_D 128
 #define DA_GMAX 8
@@ -196,27 +197,214 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 
 // One workgroup per q head; wave w merges splits w, w+4, ... with 4 loads in flight per lane, then the
 // waves merge through LDS.  Lane owns d = 2*lane, 2*lane+1.
-// NW waves per head; wave w merges splits w, w+NW, ... in batches of CB whose loads are ALL issued before anything is
-// consumed (the partials were written by other CUs: every dependent round trip here is ~1-2 us of L2/fabric latency, and the
-// kernel is nothing but such round trips).  43 splits (2k keys) on 4 waves = one batch.
+// Long-cache variant: a workgroup owns up to DA_LONG_MAX consecutive keys and walks them in passes of 64 with the same
+// staging + MFMA tile as above; each wave keeps a running (m, l, O) over its 16-key tile of every pass (online softmax),
+// so a 32k-key cache needs 128-171 partials per head instead of 512-683 and every workgroup streams 64-128 KB.
+// The K / V / cos / sin rows of pass p+1 are in flight (register double buffer, unconditional clamped loads) while pass p
+// is rotated, staged and multiplied; the slot indices of the whole range are fetched once into LDS.
+#define DA_LONG_MAX 512
+struct DaPass {
+  u32x4_t k[4], v[4], c[4], s[4];
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void decode_attn_long_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
+    const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
+    float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
+    int chunk, float scale, int max_len) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2 + 512 + DA_LONG_MAX * 4];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(lds);
+  bf16_t* Vs = Ks + 64 * DA_KLD;
+  bf16_t* Qs = Vs + 64 * DA_VLD;
+  float* Om = reinterpret_cast<float*>(lds);
+  float* Mm = reinterpret_cast<float*>(lds + 64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2);
+  float* Lm = Mm + 64;
+  int* slots_s = reinterpret_cast<int*>(lds + 64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2 + 512);
+
+  const int start = blockIdx.x * chunk;
+  const int kvh = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int srow = tid >> 4, c = tid & 15;
+  const bool upper = c >= 8;
+  const int fc = (c & 7) * 8;
+  const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D + c * 8;
+  const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D + c * 8;
+
+  for (int i = tid; i < chunk; i += 256) slots_s[i] = slot_of[min(start + i, max_len - 1)];
+  u32x4_t qraw = u32x4_t{0, 0, 0, 0};
+  if (srow < G) qraw = *reinterpret_cast<const u32x4_t*>(q + (size_t)(kvh * G + srow) * DA_D + c * 8);
+  const int L = (len_dev ? *len_dev : 0) + len_add;
+  if (start >= L) return;                                   // workgroup-uniform
+  const int n_rows = min(chunk, L - start);
+  const int n_pass = (n_rows + 63) >> 6;
+  {
+    const bf16_t* csq = rope_cs + (size_t)(L - 1) * DA_D;
+    const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + fc);
+    const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + fc);
+    u32x4_t outq = u32x4_t{0, 0, 0, 0};
+    u32x4_t rp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rp[i] = dpp_u<0x128>(qraw[i]);
+    if (srow < G) {
+      float x[8], xp[8], cc[8], sn[8], o[8];
+      unpack8(qraw, x); unpack8(rp, xp); unpack8(qc, cc); unpack8(qs, sn);
+      rope8(x, xp, cc, sn, upper, o);
+      outq = pack8(o);
+    }
+    *reinterpret_cast<u32x4_t*>(Qs + srow * DA_KLD + c * 8) = outq;
+  }
+  __syncthreads();                                          // slots_s and Qs visible
+
+  auto load_pass = [&](int p, DaPass& b) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lr = min(p * 64 + it * 16 + srow, n_rows - 1);      // clamped: rows past the end are zeroed when staged
+      const int slot = slots_s[lr];
+      b.k[it] = *reinterpret_cast<const u32x4_t*>(kp + (size_t)slot * DA_D);
+      b.v[it] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)slot * DA_D);
+      const bf16_t* csr = rope_cs + (size_t)(start + lr) * DA_D;
+      b.c[it] = *reinterpret_cast<const u32x4_t*>(csr + fc);
+      b.s[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
+    }
+  };
+  auto stage = [&](int p, const DaPass& b) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lrow = it * 16 + srow;
+      u32x4_t kp4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) kp4[i] = dpp_u<0x128>(b.k[it][i]);
+      float x[8], xp[8], cc[8], sn[8], o[8];
+      unpack8(b.k[it], x); unpack8(kp4, xp); unpack8(b.c[it], cc); unpack8(b.s[it], sn);
+      rope8(x, xp, cc, sn, upper, o);
+      const bool ok = p * 64 + lrow < n_rows;
+      const u32x4_t z = u32x4_t{0, 0, 0, 0};
+      *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = ok ? pack8(o) : z;
+      *reinterpret_cast<u32x4_t*>(Vs + lrow * DA_VLD + c * 8) = ok ? b.v[it] : z;
+    }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  float m_w = -1e30f, l_w = 0.f;
+  f32x4_t oacc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int p) {
+    const int base = p * 64 + wave * 16;                    // this wave's tile of the pass
+    if (base >= n_rows) return;                             // wave-uniform
+    f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + (wave * 16 + fr) * DA_KLD + ks * 32 + fq * 8);
+      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(Qs + fr * DA_KLD + ks * 32 + fq * 8);
+      sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, sacc, 0, 0, 0);
+    }
+    float sc[4], mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = base + fq * 4 + r < n_rows;
+      sc[r] = ok ? sacc[r] * scale : -1e30f;
+      mx = fmaxf(mx, sc[r]);
+    }
+    const float m_new = fmaxf(m_w, xor32_max(xor16_max(mx)));
+    const float alpha = __expf(m_w - m_new);
+    float p8[8], rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p8[r] = sc[r] > -1e29f ? __expf(sc[r] - m_new) : 0.f;
+      p8[r + 4] = 0.f;
+      rs += p8[r];
+    }
+    l_w = l_w * alpha + xor32_sum(xor16_sum(rs));
+    m_w = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+    u32x4_t pk = pack8(p8);
+    const bf16x8_t pb = *reinterpret_cast<bf16x8_t*>(&pk);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16_t* vr = Vs + (wave * 16 + fq * 4 + (fr >> 2)) * DA_VLD + dt * 16 + (fr & 3) * 4;
+      const v4s_da_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_da_t*)(vr));
+      const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], lo[0], lo[1], lo[2], lo[3]};
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
+    }
+  };
+
+  DaPass A, B;
+  load_pass(0, A);
+  for (int p = 0; p < n_pass; p += 2) {
+    load_pass(min(p + 1, n_pass - 1), B);                   // unconditional: a redundant reload at the end costs nothing
+    __builtin_amdgcn_sched_barrier(0);
+    stage(p, A);
+    lds_barrier();
+    compute(p);
+    lds_barrier();
+    if (p + 1 >= n_pass) break;
+    load_pass(min(p + 2, n_pass - 1), A);
+    __builtin_amdgcn_sched_barrier(0);
+    stage(p + 1, B);
+    lds_barrier();
+    compute(p + 1);
+    lds_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing redundant loads must not outlive the wave's registers
+  if (fr < G) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_D) + dt * 16 + fq * 4) = oacc[dt];
+    if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
+  }
+  __syncthreads();
+  const size_t part = (size_t)blockIdx.x * Hq;
+  for (int idx = tid; idx < G * DA_D; idx += 256) {
+    const int g = idx / DA_D, d = idx % DA_D;
+    float mn = Mm[g];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) mn = fmaxf(mn, Mm[w * 16 + g]);
+    float l = 0.f, a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = __expf(Mm[w * 16 + g] - mn);
+      l += Lm[w * 16 + g] * e;
+      a += Om[(w * 16 + g) * DA_D + d] * e;
+    }
+    const int hq = kvh * G + g;
+    ws_acc[(part + hq) * DA_D + d] = a;
+    if (d == 0) { ws_m[part + hq] = mn; ws_l[part + hq] = l; }
+  }
+}
+
+// Merge of the splits.  grid = (Hq, DS): a workgroup owns 128/DS output columns of one head, so a long cache's partials
+// (3 MB at 32k keys) are pulled by DS x Hq CUs instead of Hq.  Inside a wave the 64 lanes are 64/CW split sub-slots x CW
+// column pairs (CW = 64/DS): wave w, sub-slot j covers splits (w*SUB + j) + NW*SUB*u, in batches of DA_CB whose loads are ALL
+// issued before anything is consumed (the partials were written by other CUs: every dependent round trip is ~1-2 us of
+// L2/fabric latency, and the kernel is nothing but such round trips).  43 splits (2k keys) on 4 waves = one batch.
 #define DA_CB 12
-template <int NW>
+template <int NW, int DS>
 __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
                                                                       const float* __restrict__ ws_acc, const int* __restrict__ len_dev,
                                                                       int len_add, bf16_t* __restrict__ out, int Hq, int chunk) {
+  constexpr int CW = 64 / DS;            // lanes across the workgroup's columns (2 columns each)
+  constexpr int SUB = DS;                // split sub-slots per wave
+  constexpr int STRIDE = NW * SUB;       // splits covered per step of u
   const int L = (len_dev ? *len_dev : 0) + len_add;
   const int ns = (L + chunk - 1) / chunk;
   const int hq = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = lane % CW, sub = lane / CW;
+  const int col = blockIdx.y * (DA_D / DS) + 2 * cl;
+  const int first = wave * SUB + sub;
   float m_[DA_CB], l_[DA_CB];
   float2 v_[DA_CB];
 #pragma unroll
   for (int u = 0; u < DA_CB; ++u) {
-    const int i0 = min(wave + NW * u, ns - 1);
+    const int i0 = min(first + STRIDE * u, ns - 1);
     const size_t p = (size_t)i0 * Hq + hq;
     m_[u] = ws_m[p];
     l_[u] = ws_l[p];
-    v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + 2 * lane);
+    v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + col);
   }
   // global max over splits (every wave computes it redundantly: ns floats)
   float mx = -1e30f;
@@ -227,32 +415,37 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
   for (int base = 0;;) {
 #pragma unroll
     for (int u = 0; u < DA_CB; ++u) {
-      if (base + wave + NW * u < ns) {
+      if (base + first + STRIDE * u < ns) {
         const float e = __expf(m_[u] - mx);
         l += l_[u] * e;
         a0 += v_[u].x * e;
         a1 += v_[u].y * e;
       }
     }
-    base += NW * DA_CB;
+    base += STRIDE * DA_CB;
     if (base >= ns) break;
 #pragma unroll
     for (int u = 0; u < DA_CB; ++u) {
-      const int i0 = min(base + wave + NW * u, ns - 1);
+      const int i0 = min(base + first + STRIDE * u, ns - 1);
       const size_t p = (size_t)i0 * Hq + hq;
       m_[u] = ws_m[p];
       l_[u] = ws_l[p];
-      v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + 2 * lane);
+      v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + col);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  // fold the sub-slots of the wave (lanes cl, cl + CW, ...), then the waves through LDS
+  if constexpr (DS >= 2) { l += __shfl_xor(l, 32, 64); a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); }
+  if constexpr (DS >= 4) { l += __shfl_xor(l, 16, 64); a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); }
   __shared__ float sl[NW];
-  __shared__ float sa[NW][DA_D];
+  __shared__ float sa[NW][DA_D / DS];
   if (lane == 0) sl[wave] = l;
-  sa[wave][2 * lane] = a0;
-  sa[wave][2 * lane + 1] = a1;
+  if (sub == 0) {
+    sa[wave][2 * cl] = a0;
+    sa[wave][2 * cl + 1] = a1;
+  }
   __syncthreads();
-  if (threadIdx.x < DA_D) {
+  if (threadIdx.x < DA_D / DS) {
     const int d = threadIdx.x;
     float lt = 0.f, at = 0.f;
 #pragma unroll
@@ -260,7 +453,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
       lt += sl[w];
       at += sa[w][d];
     }
-    out[(size_t)hq * DA_D + d] = f2bf(at / lt);
+    out[(size_t)hq * DA_D + blockIdx.y * (DA_D / DS) + d] = f2bf(at / lt);
   }
 }
 
@@ -275,7 +468,10 @@ template <int G>
 static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* kp, const bf16_t* vp, const int* slot_of,
                          const bf16_t* cs, const int* len_dev, int len_add, float* ws_m, float* ws_l, float* ws_acc, int Hq, int Hkv,
                          int n_slots, int chunk, float scale, int max_len) {
-  decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+  if (chunk > 16 * DA_MAX_STEPS)
+    decode_attn_long_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+  else
+    decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
 }
 
 extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of,
@@ -283,8 +479,10 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
                                          int Hq, int Hkv, int D, int n_slots, int max_len, int chunk, float scale, void* stream) {
   SVLM_CHECK_ARG(D == DA_D, "svlm_decode_attn_ropeload: head_dim %d unsupported (128 only)", D);
   SVLM_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DA_GMAX, "svlm_decode_attn_ropeload: Hq=%d Hkv=%d (group must be <= %d)", Hq, Hkv, DA_GMAX);
-  SVLM_CHECK_ARG(chunk > 0 && chunk % 16 == 0 && chunk <= 16 * DA_MAX_STEPS && max_len > 0 && n_slots > 0,
-                 "svlm_decode_attn_ropeload: chunk=%d must be a multiple of 16 in [16, %d]", chunk, 16 * DA_MAX_STEPS);
+  SVLM_CHECK_ARG(chunk > 0 && max_len > 0 && n_slots > 0 &&
+                     ((chunk % 16 == 0 && chunk <= 16 * DA_MAX_STEPS) || (chunk % 64 == 0 && chunk <= DA_LONG_MAX)),
+                 "svlm_decode_attn_ropeload: chunk=%d must be a multiple of 16 up to %d or a multiple of 64 up to %d", chunk,
+                 16 * DA_MAX_STEPS, DA_LONG_MAX);
   SVLM_CHECK_ARG(len_dev != nullptr || (len_add > 0 && len_add <= max_len), "svlm_decode_attn_ropeload: length %d outside (0, %d]", len_add, max_len);
   const int ns = (max_len + chunk - 1) / chunk;
   float* ws_m = (float*)ws;
@@ -301,9 +499,16 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
 #undef SVLM_DA_CASE
   int rc = svlm_check_launch("svlm_decode_attn_ropeload(split)");
   if (rc) return rc;
-  if ((max_len + chunk - 1) / chunk <= 4 * DA_CB * 2)      // up to two batches per wave: 4 waves; long caches: 16
-    decode_attn_combine_kernel<4><<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
-  else
-    decode_attn_combine_kernel<16><<<Hq, 1024, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+  static const int force_ds = getenv("SVLM_DA_COMBINE_DS") ? atoi(getenv("SVLM_DA_COMBINE_DS")) : 0;
+  const int ns_max = (max_len + chunk - 1) / chunk;
+  // measured on MI355X (tools/decode_attn_sweep.py): column halves pay from ~64 splits (7B @ window 4096: 13.8 -> 12.3 us),
+  // column quarters on 16 waves from ~200 (32k keys: 26.3 -> 22.8 us); below that the extra workgroups only add latency
+  if (force_ds == 4 || (force_ds == 0 && ns_max > 192)) {
+    decode_attn_combine_kernel<16, 4><<<dim3(Hq, 4), 1024, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+  } else if (force_ds == 2 || (force_ds == 0 && ns_max > 64)) {
+    decode_attn_combine_kernel<4, 2><<<dim3(Hq, 2), 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+  } else {                     // bounded windows: up to two batches per wave on 4 waves
+    decode_attn_combine_kernel<4, 1><<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+  }
   return svlm_check_launch("svlm_decode_attn_ropeload(combine)");
 }

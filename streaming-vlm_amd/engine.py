@@ -104,9 +104,7 @@ class SvlmEngine:
         self.max_len = int(max_len)
         self.max_new = int(max_new_tokens)
         if decode_chunk is None:
-            # split-KV chunk: ~64 splits per kv head at the bounded window (measured best on MI355X: 48 keys for
-            # 2B @ window 2048; fewer, fatter splits starve the chip, more of them bloat the combine)
-            decode_chunk = max(16, min(64, 16 * int(math.ceil(self.max_len / 64 / 16))))
+            decode_chunk = self.pick_decode_chunk(self.max_len, tc.num_kv_heads)
         self.decode_chunk = int(os.environ.get("SVLM_DECODE_CHUNK", decode_chunk))
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
         # EXPERIMENT, off by default: Infinity-Cache prefetch of layer l+1's weights on a side stream while layer l computes.
@@ -150,6 +148,18 @@ class SvlmEngine:
         self._graph_key = None
         self._penalty = 1.0
         self._suppress = None
+
+    @staticmethod
+    def pick_decode_chunk(max_len: int, n_kv_heads: int) -> int:
+        """Keys per decode-attention workgroup (measured on MI355X, tools/decode_attn_sweep.py): 48 at the bounded windows
+        of the streaming configs (2B @ 2048: 8.5 us, 7B @ 4096: 12.3 us; fewer, fatter splits starve the chip, more of them
+        bloat the combine), 64 for long caches, and the multi-pass kernel (256 keys) once there are >= 4 kv heads of a
+        32k-class cache, where one-pass splits would mean thousands of partials."""
+        if max_len <= 1024:
+            return max(16, 16 * int(math.ceil(max_len / 64 / 16)))
+        if max_len <= 6144:
+            return 48
+        return 256 if max_len * n_kv_heads >= 100_000 else 64
 
     # ------------------------------------------------------------------ cache
     def new_cache(self, page_tokens: int = 16, slack: float = 1.0) -> KVPool:

@@ -214,7 +214,10 @@ def _attn_setup(Hq, Hkv, L, cap, seed):
 
 
 @pytest.mark.parametrize("Hq,Hkv,L,chunk", [(12, 2, 2352, 64), (12, 2, 2352, 32), (28, 4, 4400, 64), (4, 2, 1, 16), (4, 2, 17, 16),
-                                            (12, 2, 100, 32), (8, 1, 333, 48), (12, 2, 2052, 16), (3, 1, 70, 64), (10, 2, 130, 64)])
+                                            (12, 2, 100, 32), (8, 1, 333, 48), (12, 2, 2052, 16), (3, 1, 70, 64), (10, 2, 130, 64),
+                                            # multi-pass (long-cache) kernel: full / ragged last pass, one pass only, odd pass counts, G=7
+                                            (12, 2, 9000, 256), (12, 2, 300, 128), (28, 4, 4400, 128), (4, 2, 65, 128), (8, 1, 1000, 512),
+                                            (4, 2, 3, 128), (12, 2, 2352, 192), (6, 1, 8191, 512)])
 def test_decode_attn(ops, ref, Hq, Hkv, L, chunk):
     cap = ((L + 63) // 64) * 64 + 64
     pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 10)
