@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--model", default="2b", choices=["2b", "7b", "tiny"])
+    ap.add_argument("--model", default="2b", choices=["2b", "7b", "tiny", "2.5-3b", "2.5-7b"])
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--fps", type=float, default=1.0)
     ap.add_argument("--sink", type=int, default=4)
@@ -67,7 +67,7 @@ def main():
     from streaming_vlm_amd.synthetic import DeviceFrameProcessor, PinnedVideo, ResidentProcessor, ResidentVideo
     from streaming_vlm_amd.weights import random_state_dict
 
-    cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "tiny": C.tiny}[args.model]()
+    cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "tiny": C.tiny, "2.5-3b": C.qwen2_5_vl_3b, "2.5-7b": C.qwen2_5_vl_7b}[args.model]()
     n_chunks = args.warmup + args.steps
     tok_per_frame = (args.size // 28) ** 2
     chunk_tokens = tok_per_frame + 24 + args.new_tokens
@@ -105,7 +105,8 @@ def main():
             log("timed region starts")
             t["t0"] = time.perf_counter()
 
-    S.streaming_inference(model=model, processor=proc, video=video, model_base="Qwen2", duration=n_chunks, previous_text="",
+    S.streaming_inference(model=model, processor=proc, video=video, model_base="Qwen2_5" if cfg.family == "qwen2_5" else "Qwen2",
+                          duration=n_chunks, previous_text="",
                           kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=False,
                           max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk,
                           ids_log=kvlog)

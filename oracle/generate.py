@@ -21,7 +21,7 @@ import torch
 
 from . import kv_policy, qwen_range as qr
 from .model import ModelCfg, model_forward
-from .rope_index import get_rope_index
+from .rope_index import get_1d_rope_index, get_rope_index, get_rope_index_2_5
 
 
 def repetition_penalty(logits_f32: torch.Tensor, ids, penalty: float):
@@ -45,7 +45,7 @@ class GenOut:
 def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=None, grid_thw=None,
              max_new_tokens=20, rep_penalty=1.05, eos_ids=(151645, 151643), suppress_eos=False,
              do_sample=False, temperature=1.0, generator: Optional[torch.Generator] = None,
-             keep_logits=False) -> GenOut:
+             keep_logits=False, all_text=False, second_per_grid_t=1.0) -> GenOut:
     """One ``model.generate(**inputs, past_key_values=kv, streaming_args=...)`` call."""
     ids = list(ids)
     sa_ids = list(ids)                       # streaming_args.input_ids (padded with 0 per forward)
@@ -55,8 +55,14 @@ def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=
     while True:
         kv_len = kv.get_seq_length()
         new_ids = ids[kv_len:]                                              # prepare_generation.py:31-35
-        pos3 = get_rope_index(sa_ids, video_grid_thw, cfg.vision.spatial_merge_size,
-                              cfg.video_token_id, cfg.vision_start_token_id)   # model_forward.py:119-126
+        if all_text:                                                        # qwen2_5/model_forward.py:99
+            pos3 = get_1d_rope_index(len(sa_ids))
+        elif cfg.vision.arch == "qwen2_5":                                  # qwen2_5/model_forward.py:101-110
+            pos3 = get_rope_index_2_5(sa_ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id,
+                                      cfg.vision_start_token_id, second_per_grid_t, cfg.vision.tokens_per_second)
+        else:
+            pos3 = get_rope_index(sa_ids, video_grid_thw, cfg.vision.spatial_merge_size,
+                                  cfg.video_token_id, cfg.vision_start_token_id)   # model_forward.py:119-126
         has_vid = cfg.video_token_id in new_ids
         logits = model_forward(w, cfg, new_ids, kv, pos3,
                                pixel_values if (first and has_vid) else None,
@@ -97,6 +103,8 @@ class StreamCfg:
     suppress_eos: bool = False
     assistant_start_bias: int = 3         # len(tok("<|im_start|>assistant\n"))  inference.py:228
     assistant_end_bias: int = 2           # len(tok(" ...<|im_end|>"))           inference.py:229
+    all_text: bool = False                # StreamingArgs.all_text: 1-D rope (qwen2_5/model_forward.py:99)
+    second_per_grid_t: float = 1.0        # 2 / FPS (qwen2_5/pos_emb.py:107-108)
 
 
 def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
@@ -133,7 +141,8 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
         grids = grids + [list(g) for g in grid]                             # :411-416 (never pruned)
         cur_len = len(ids)
         out = generate(w, cfg, ids, kv, grids, pix, grid, scfg.max_new_tokens, scfg.repetition_penalty,
-                       suppress_eos=scfg.suppress_eos, keep_logits=keep_logits)
+                       suppress_eos=scfg.suppress_eos, keep_logits=keep_logits, all_text=scfg.all_text,
+                       second_per_grid_t=scfg.second_per_grid_t)
         gen = out.sequences
         if gen[-1] != qr.IM_END:                                            # :457-459
             gen = gen + [qr.IM_END]

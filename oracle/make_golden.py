@@ -103,6 +103,15 @@ def gen_reference_vectors():
         json.dump(rope, f)
     with open(os.path.join(OUT, "ref_sec2ts.json"), "w") as f:
         json.dump({str(s): ref_sec2ts(s) for s in [0, 0.5, 1.0, 59.999, 61.25, 3600, 3661.5, 86399.001]}, f)
+    # Qwen2.5 `all_text` positions (StreamingArgs.all_text, qwen2_5/model_forward.py:6-28,99)
+    from streaming_vlm.inference.qwen2_5.model_forward import get_1d_rope_index as ref_1d
+    one_d = {}
+    for name in ("two_rounds", "vision_first"):
+        ids = torch.tensor([seqs[name]])
+        pos, delta = ref_1d(ids, None, None, None, torch.ones_like(ids))
+        one_d[name] = {"n": len(seqs[name]), "pos": pos[:, 0].tolist(), "delta": int(delta.flatten()[0])}
+    with open(os.path.join(OUT, "ref_rope_1d.json"), "w") as f:
+        json.dump(one_d, f)
     print("reference vectors: ranges", sum(len(v["cases"]) for v in ranges.values()), "cases; rope", len(rope), "sequences")
 
 
@@ -164,6 +173,63 @@ def gen_hf_vectors():
     print("hf vectors:", {k: v.shape for k, v in out.items()})
 
 
+def gen_hf_vectors_2_5():
+    """Tiny stock Qwen2.5-VL vision tower + get_rope_index (transformers as installed): the third-party code behind the
+    reference's qwen2_5/ patches.  Ragged windows on purpose: a (2, 8, 6) grid with 56-px windows."""
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    import transformers
+    from streaming_vlm_amd import config as C
+    from streaming_vlm_amd.weights import random_state_dict
+
+    cfg = C.tiny_2_5()
+    cfg.text.num_heads, cfg.text.num_kv_heads = 2, 1
+    vc = cfg.vision
+    hf_cfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, intermediate_size=512,
+                         vocab_size=cfg.text.vocab_size, rms_norm_eps=1e-6, tie_word_embeddings=True,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]}),
+        vision_config=dict(depth=vc.depth, hidden_size=vc.embed_dim, num_heads=vc.num_heads, intermediate_size=vc.mlp_hidden,
+                           out_hidden_size=vc.out_hidden, patch_size=14, temporal_patch_size=2, spatial_merge_size=2,
+                           in_channels=3, window_size=vc.window_size, fullatt_block_indexes=list(vc.fullatt_block_indexes),
+                           hidden_act="silu", tokens_per_second=2),
+        tie_word_embeddings=True)
+    hf_cfg._attn_implementation = "eager"
+    model = Qwen2_5_VLForConditionalGeneration(hf_cfg).to(torch.float32).eval()
+    sd = random_state_dict(cfg, 7, "cpu", dtype=torch.float32)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not [m for m in missing if "lm_head" not in m and "inv_freq" not in m], missing
+    assert not unexpected, unexpected
+    g = torch.Generator().manual_seed(13)
+    out = {}
+    with torch.no_grad():
+        for tag, grid in (("a", [[2, 8, 6]]), ("b", [[1, 4, 4], [1, 4, 4]])):
+            gt = torch.tensor(grid)
+            n = int(sum(t * h * w for t, h, w in grid))
+            pix = torch.randn(n, vc.patch_dim, generator=g)
+            vis = model.model.visual(pix, grid_thw=gt)
+            vis = vis.pooler_output if hasattr(vis, "pooler_output") else vis
+            out[f"vit_pix_{tag}"], out[f"vit_grid_{tag}"], out[f"vit_out_{tag}"] = pix.numpy(), gt.numpy(), vis.float().numpy()
+        # M-RoPE ids with a float temporal step: second_per_grid_ts = 1.0 and 0.5, tokens_per_second = 2
+        VS, VP, VE = cfg.vision_start_token_id, cfg.video_token_id, 151653
+        ids = [1, 2, 3, VS] + [VP] * 12 + [VE, 7, 8, VS] + [VP] * 24 + [VE, 9]
+        grids = [[1, 8, 6], [2, 8, 6]]
+        for tag, spg in (("1", 1.0), ("h", 0.5)):
+            kw = dict(input_ids=torch.tensor([ids]), video_grid_thw=torch.tensor(grids), second_per_grid_ts=torch.tensor([spg, spg]),
+                      attention_mask=torch.ones(1, len(ids), dtype=torch.long))
+            try:
+                pos, _ = model.model.get_rope_index(**kw)
+            except TypeError:      # newer signatures want the modality map
+                mm = torch.tensor([[2 if t == VP else 0 for t in ids]])
+                pos, _ = model.model.get_rope_index(mm_token_type_ids=mm, **kw)
+            out[f"rope_pos_{tag}"] = pos[:, 0].float().numpy()
+        out["rope_ids"], out["rope_grids"] = np.array(ids), np.array(grids)
+    np.savez_compressed(os.path.join(OUT, "hf_tiny_modules_2_5.npz"), **out)
+    with open(os.path.join(OUT, "hf_tiny_modules_2_5.json"), "w") as f:
+        json.dump({"transformers": transformers.__version__, "torch": torch.__version__, "weights_seed": 7, "dtype": "float32",
+                   "note": "weights = streaming_vlm_amd.weights.random_state_dict(tiny_2_5(heads=2,kv=1), seed 7, fp32)"}, f)
+    print("hf 2.5 vectors:", {k: v.shape for k, v in out.items()})
+
+
 def gen_oracle_vectors():
     import helpers as H
     from streaming_vlm_amd import config as C
@@ -185,6 +251,19 @@ def gen_oracle_vectors():
         n = 20 if "default" in name else (32 if name.startswith("cfg0") else 10)
         o = H.run_oracle_stream(cfg, sd, n, **kw)
         runs[name] = {"kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"]}
+    # Qwen2.5-VL family (tiny_2_5: windowed RMSNorm/SwiGLU tower, float temporal M-RoPE); frames of 112x84 have ragged windows
+    cfg25 = C.tiny_2_5()
+    sd25 = random_state_dict(cfg25, 0, "cpu")
+    for name, kw in {
+        "q25_sink4_win64": dict(policy="sink_window", sink=4, window=64),
+        "q25_ragged_sink4_win96": dict(policy="sink_window", sink=4, window=96, size=[112, 84]),
+        "q25_structural_t2_v3": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+                                     previous_text="a b c d e f g h i j k l m n o p"),
+        "q25_all_text": dict(policy="sink_window", sink=4, window=64, all_text=True),
+    }.items():
+        o = H.run_oracle_stream(cfg25, sd25, 10, **kw)
+        runs[name] = {"model": "tiny_2_5", "kwargs": kw, "n_chunks": 10, "trace": o["trace"], "kv_len": o["kv_len"],
+                      "new_tokens": o["new_tokens"]}
     with open(os.path.join(OUT, "oracle_streams.json"), "w") as f:
         json.dump(runs, f)
     print("oracle vectors:", list(runs))
@@ -195,4 +274,5 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     gen_reference_vectors()
     gen_hf_vectors()
+    gen_hf_vectors_2_5()
     gen_oracle_vectors()

@@ -38,6 +38,12 @@ class VisionCfg:
     temporal_patch_size: int = 2
     spatial_merge_size: int = 2
     in_channels: int = 3
+    # Qwen2.5-VL tower (qwen2_5/vision_forward.py): RMSNorm + SwiGLU blocks, windowed attention
+    arch: str = "qwen2"
+    window_size: int = 112
+    fullatt_block_indexes: tuple = (7, 15, 23, 31)
+    out_hidden: int = 0
+    tokens_per_second: float = 2.0
 
 
 @dataclass
@@ -141,8 +147,85 @@ def quick_gelu(x):
     return x * torch.sigmoid(1.702 * x)
 
 
+def get_window_index(grid_thw, merge: int, window_size: int, patch: int):
+    """Qwen2_5_VisionTransformerPretrainedModel.get_window_index as the reference calls it
+    (qwen2_5/vision_forward.py:65-69; transformers 4.52 modeling_qwen2_5_vl.py, same arithmetic as
+    transformers.vision_utils.get_vision_window_index in 5.x): window_index over MERGED tokens and
+    cu_window_seqlens in patches, duplicates removed (unique_consecutive, :69)."""
+    window_index, cu = [], [0]
+    wid = 0
+    vw = window_size // merge // patch
+    unit = merge * merge
+    for t, h, w in [[int(v) for v in g] for g in grid_thw]:
+        gh, gw = h // merge, w // merge
+        index = torch.arange(t * gh * gw).reshape(t, gh, gw)
+        pad_h = vw - gh % vw
+        pad_w = vw - gw % vw
+        nh, nw = (gh + pad_h) // vw, (gw + pad_w) // vw
+        padded = F.pad(index, (0, pad_w, 0, pad_h), "constant", -100)
+        padded = padded.reshape(t, nh, vw, nw, vw).permute(0, 1, 3, 2, 4).reshape(t, nh * nw, vw, vw)
+        seqlens = (padded != -100).sum([2, 3]).reshape(-1)
+        padded = padded.reshape(-1)
+        window_index.append(padded[padded != -100] + wid)
+        cu.extend((seqlens.cumsum(0) * unit + cu[-1]).tolist())
+        wid += t * gh * gw
+    cu = torch.unique_consecutive(torch.tensor(cu, dtype=torch.int32))
+    return torch.cat(window_index, 0), cu.tolist()
+
+
+def vit_forward_2_5(w: dict, cfg: ModelCfg, pixel_values, grid_thw, prefix="model.visual."):
+    """Qwen2.5-VL tower: streaming_visual_encoder_forward / block / attention of the reference
+    (qwen2_5/vision_forward.py:53-102, 36-50, 6-34) over the stock modules Qwen2_5_VLVisionBlock (RMSNorm, SwiGLU MLP with
+    biases), Qwen2_5_VLPatchMerger (RMSNorm ln_q) -- transformers modeling_qwen2_5_vl.py."""
+    vc = cfg.vision
+    dt = w[prefix + "patch_embed.proj.weight"].dtype
+    E, hd = vc.embed_dim, vc.embed_dim // vc.num_heads
+    unit = vc.spatial_merge_size ** 2
+    x = F.linear(pixel_values.to(dt), w[prefix + "patch_embed.proj.weight"].reshape(E, -1))
+    N = x.shape[0]
+    freqs = vit_rot_pos_emb(grid_thw, hd, vc.spatial_merge_size)
+    window_index, cu_window = get_window_index(grid_thw, vc.spatial_merge_size, vc.window_size, vc.patch_size)
+    x = x.reshape(N // unit, unit, -1)[window_index].reshape(N, -1)
+    freqs = freqs.reshape(N // unit, unit, -1)[window_index].reshape(N, -1)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    cos, sin = emb.cos(), emb.sin()
+    cu_full = [0]
+    for t, h, ww in [[int(v) for v in g] for g in grid_thw]:
+        for _ in range(t):
+            cu_full.append(cu_full[-1] + h * ww)
+    scale = 1.0 / math.sqrt(hd)
+    for b in range(vc.depth):
+        p = f"{prefix}blocks.{b}."
+        cu = cu_full if b in vc.fullatt_block_indexes else cu_window
+        h1 = rms_norm(x, w[p + "norm1.weight"], 1e-6)
+        qkv = F.linear(h1, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"])
+        q, k, v = qkv.reshape(N, 3, vc.num_heads, hd).permute(1, 0, 2, 3).unbind(0)
+        # apply_rotary_pos_emb_flashatt / apply_rotary_pos_emb_vision: fp32 math, one rounding
+        qf, kf = q.float(), k.float()
+        c, s_ = cos.unsqueeze(-2), sin.unsqueeze(-2)
+        q = (qf * c + rotate_half(qf) * s_).to(dt)
+        k = (kf * c + rotate_half(kf) * s_).to(dt)
+        outs = []
+        for a0, a1 in zip(cu[:-1], cu[1:]):
+            qs, ks, vs = (t_[a0:a1].transpose(0, 1) for t_ in (q, k, v))
+            outs.append(flash_attention(qs, ks, vs, None, scale).transpose(0, 1))
+        a = torch.cat(outs, 0).reshape(N, -1)
+        x = x + F.linear(a, w[p + "attn.proj.weight"], w[p + "attn.proj.bias"])
+        h2 = rms_norm(x, w[p + "norm2.weight"], 1e-6)
+        g = F.linear(h2, w[p + "mlp.gate_proj.weight"], w[p + "mlp.gate_proj.bias"])
+        u = F.linear(h2, w[p + "mlp.up_proj.weight"], w[p + "mlp.up_proj.bias"])
+        x = x + F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"], w[p + "mlp.down_proj.bias"])
+    m = prefix + "merger."
+    x = rms_norm(x, w[m + "ln_q.weight"], 1e-6).view(-1, E * unit)
+    x = F.gelu(F.linear(x, w[m + "mlp.0.weight"], w[m + "mlp.0.bias"]))
+    x = F.linear(x, w[m + "mlp.2.weight"], w[m + "mlp.2.bias"])
+    return x[torch.argsort(window_index)]
+
+
 def vit_forward(w: dict, cfg: ModelCfg, pixel_values, grid_thw, prefix="model.visual."):
     """streaming_visual_encoder_forward (qwen2/vision_forward.py:53-80)."""
+    if cfg.vision.arch == "qwen2_5":
+        return vit_forward_2_5(w, cfg, pixel_values, grid_thw, prefix)
     vc = cfg.vision
     dt = w[prefix + "patch_embed.proj.weight"].dtype
     pw = w[prefix + "patch_embed.proj.weight"].reshape(vc.embed_dim, -1)

@@ -13,7 +13,8 @@ from .config import ModelConfig, TextConfig, VisionConfig, qwen2_vl_2b, qwen2_vl
 from .spans import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range  # noqa: F401
 from .kv_pool import KVPool  # noqa: F401
 from .engine import SvlmEngine  # noqa: F401
-from .model import StreamingArgs, StreamingQwen2VL, convert_qwen2_to_streaming, streaming_generate  # noqa: F401
+from .model import (StreamingArgs, StreamingQwen2VL, convert_qwen2_5_to_streaming, convert_qwen2_to_streaming,  # noqa: F401
+                    streaming_generate)
 from .driver import (contiguous_id_and_kv, load_model_and_processor, open_vtt, process_past_kv, prune_id_and_kv_cache,  # noqa: F401
                      resort_id_and_kv, sec2ts, sink_window_evict, streaming_inference)
 from .synthetic import (DeviceFrameProcessor, PinnedVideo, SyntheticProcessor, SyntheticVideo, patchify,  # noqa: F401

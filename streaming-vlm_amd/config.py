@@ -25,6 +25,18 @@ class VisionConfig:
     temporal_patch_size: int = 2
     spatial_merge_size: int = 2
     in_channels: int = 3
+    # Qwen2.5-VL tower: RMSNorm + SwiGLU blocks, windowed attention except in `fullatt_block_indexes`,
+    # merger output `out_hidden`; `mlp_hidden` is then the SwiGLU intermediate size (3420 for the released checkpoints)
+    arch: str = "qwen2"
+    window_size: int = 112
+    fullatt_block_indexes: tuple = (7, 15, 23, 31)
+    out_hidden: int = 0
+    tokens_per_second: float = 2.0
+
+    @property
+    def mlp_padded(self):
+        """SwiGLU intermediate size rounded up to 8 columns (16-B rows for the GEMM); the pad rows/columns are zero."""
+        return (self.mlp_hidden + 7) // 8 * 8
 
     @property
     def head_dim(self):
@@ -59,6 +71,10 @@ class ModelConfig:
     eos_token_ids: tuple = (IM_END, ENDOFTEXT)
     name: str = "qwen2-vl"
 
+    @property
+    def family(self) -> str:
+        return "qwen2_5" if self.vision.arch == "qwen2_5" else "qwen2"
+
 
 def qwen2_vl_2b() -> ModelConfig:
     return ModelConfig(VisionConfig(), TextConfig(), name="Qwen2-VL-2B")
@@ -68,6 +84,28 @@ def qwen2_vl_7b() -> ModelConfig:
     return ModelConfig(VisionConfig(), TextConfig(hidden_size=3584, num_layers=28, num_heads=28, num_kv_heads=4,
                                                   intermediate_size=18944, vocab_size=152064, tie_word_embeddings=False),
                        name="Qwen2-VL-7B")
+
+
+def qwen2_5_vl_7b() -> ModelConfig:
+    """Qwen2.5-VL-7B / the released StreamingVLM checkpoint (model-card values)."""
+    return ModelConfig(VisionConfig(arch="qwen2_5", mlp_hidden=3420, out_hidden=3584),
+                       TextConfig(hidden_size=3584, num_layers=28, num_heads=28, num_kv_heads=4, intermediate_size=18944,
+                                  vocab_size=152064, tie_word_embeddings=False), name="Qwen2.5-VL-7B")
+
+
+def qwen2_5_vl_3b() -> ModelConfig:
+    return ModelConfig(VisionConfig(arch="qwen2_5", mlp_hidden=3420, out_hidden=2048),
+                       TextConfig(hidden_size=2048, num_layers=36, num_heads=16, num_kv_heads=2, intermediate_size=11008,
+                                  vocab_size=151936, tie_word_embeddings=True), name="Qwen2.5-VL-3B")
+
+
+def tiny_2_5(depth=4, layers=2, vocab=151680) -> ModelConfig:
+    """Qwen2.5-style tiny geometry: RMSNorm/SwiGLU tower with an intermediate size that needs padding (100 -> 104),
+    windowed blocks with one full-attention block, 56-px windows (2x2 merged tokens)."""
+    return ModelConfig(VisionConfig(arch="qwen2_5", depth=depth, embed_dim=160, num_heads=2, mlp_hidden=100, out_hidden=256,
+                                    window_size=56, fullatt_block_indexes=(1,)),
+                       TextConfig(hidden_size=256, num_layers=layers, num_heads=4, num_kv_heads=2, intermediate_size=512,
+                                  vocab_size=vocab, tie_word_embeddings=True), name="tiny-2.5")
 
 
 def tiny(depth=2, layers=2, vocab=151680) -> ModelConfig:
@@ -89,13 +127,25 @@ def from_hf_config(hf) -> ModelConfig:
                       num_kv_heads=tc.num_key_value_heads, head_dim=head_dim, intermediate_size=tc.intermediate_size,
                       vocab_size=tc.vocab_size, rms_eps=tc.rms_norm_eps, rope_theta=float(theta), mrope_section=section,
                       tie_word_embeddings=bool(getattr(hf, "tie_word_embeddings", getattr(tc, "tie_word_embeddings", False))))
-    vision = VisionConfig(depth=vc.depth, embed_dim=vc.embed_dim, num_heads=vc.num_heads,
-                          mlp_hidden=int(vc.embed_dim * vc.mlp_ratio), patch_size=vc.patch_size,
-                          temporal_patch_size=vc.temporal_patch_size, spatial_merge_size=vc.spatial_merge_size,
-                          in_channels=vc.in_channels)
-    if vc.hidden_size != tc.hidden_size:
-        raise ValueError(f"merger output {vc.hidden_size} != LLM hidden {tc.hidden_size}")
-    if vc.hidden_act != "quick_gelu":
-        raise ValueError(f"unsupported ViT activation {vc.hidden_act}")
+    if hasattr(vc, "fullatt_block_indexes"):           # Qwen2_5_VLVisionConfig
+        if vc.hidden_act != "silu":
+            raise ValueError(f"unsupported Qwen2.5 ViT activation {vc.hidden_act}")
+        vision = VisionConfig(arch="qwen2_5", depth=vc.depth, embed_dim=vc.hidden_size, num_heads=vc.num_heads,
+                              mlp_hidden=vc.intermediate_size, patch_size=vc.patch_size,
+                              temporal_patch_size=vc.temporal_patch_size, spatial_merge_size=vc.spatial_merge_size,
+                              in_channels=getattr(vc, "in_channels", getattr(vc, "in_chans", 3)), window_size=vc.window_size,
+                              fullatt_block_indexes=tuple(vc.fullatt_block_indexes), out_hidden=vc.out_hidden_size,
+                              tokens_per_second=float(getattr(vc, "tokens_per_second", 2)))
+        if vc.out_hidden_size != tc.hidden_size:
+            raise ValueError(f"merger output {vc.out_hidden_size} != LLM hidden {tc.hidden_size}")
+    else:
+        vision = VisionConfig(depth=vc.depth, embed_dim=vc.embed_dim, num_heads=vc.num_heads,
+                              mlp_hidden=int(vc.embed_dim * vc.mlp_ratio), patch_size=vc.patch_size,
+                              temporal_patch_size=vc.temporal_patch_size, spatial_merge_size=vc.spatial_merge_size,
+                              in_channels=vc.in_channels)
+        if vc.hidden_size != tc.hidden_size:
+            raise ValueError(f"merger output {vc.hidden_size} != LLM hidden {tc.hidden_size}")
+        if vc.hidden_act != "quick_gelu":
+            raise ValueError(f"unsupported ViT activation {vc.hidden_act}")
     return ModelConfig(vision, text, video_token_id=hf.video_token_id, vision_start_token_id=hf.vision_start_token_id,
                        name=getattr(hf, "name_or_path", "") or "qwen2-vl")

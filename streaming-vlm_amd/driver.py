@@ -23,7 +23,7 @@ import torch
 from .config import IM_END, VIDEO_PAD, VISION_END, VISION_START
 from .spans import SYSTEM_PROMPT_OFFSET, TOKEN_IDS, get_qwen_range
 from .kv_pool import KVPool
-from .model import StreamingArgs, StreamingQwen2VL, convert_qwen2_to_streaming
+from .model import StreamingArgs, StreamingQwen2VL, convert_qwen2_5_to_streaming, convert_qwen2_to_streaming
 from .synthetic import SyntheticProcessor, SyntheticVideo
 
 TOTAL_VIDEO_DURATION = 6000
@@ -169,12 +169,18 @@ def load_model_and_processor(model_path, model_base="Qwen2_5"):
         from . import config as C
         from .weights import random_state_dict
         parts = model_path.split(":")
-        cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "tiny": C.tiny}[parts[1]]()
+        cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "tiny": C.tiny, "2.5-3b": C.qwen2_5_vl_3b, "2.5-7b": C.qwen2_5_vl_7b,
+               "tiny-2.5": C.tiny_2_5}[parts[1]]()
         seed = int(parts[2]) if len(parts) > 2 else 0
         return StreamingQwen2VL(cfg, random_state_dict(cfg, seed, "cuda"), "cuda"), SyntheticProcessor()
+    from transformers import AutoProcessor
+    if model_base == "Qwen2_5":                        # reference inference.py:72-78
+        from transformers import Qwen2_5_VLForConditionalGeneration
+        model = Qwen2_5_VLForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map="cuda")
+        return convert_qwen2_5_to_streaming(model), AutoProcessor.from_pretrained(model_path, use_fast=False)
     if model_base != "Qwen2":
-        raise NotImplementedError("only the Qwen2-VL family is on the HIP path (Qwen2.5-VL: SURVEY 8f-3)")
-    from transformers import AutoProcessor, Qwen2VLForConditionalGeneration
+        raise ValueError(f"model_base must be 'Qwen2' or 'Qwen2_5', not {model_base!r}")
+    from transformers import Qwen2VLForConditionalGeneration
     model = Qwen2VLForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map="cuda")
     return convert_qwen2_to_streaming(model), AutoProcessor.from_pretrained(model_path, use_fast=False)
 
@@ -207,8 +213,6 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         raise AssertionError("window_size must be divisible by chunk_duration")
     if test_data_json is not None:
         raise NotImplementedError("LMMDataset-driven input (training data pipeline) is outside the hot path")
-    if all_text:
-        raise NotImplementedError("all_text (1-D rope for LiveCC's training quirk) is a Qwen2.5-only switch")
     if kv_policy not in ("structural", "sink_window", "none"):
         raise ValueError(f"unknown kv_policy {kv_policy!r}")
 
@@ -216,9 +220,9 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
     if model is None or processor is None:
         model, processor = load_model_and_processor(model_path, model_base)
     elif getattr(model, "_svlm_engine", None) is None:
-        if model_base != "Qwen2":
-            raise NotImplementedError("only the Qwen2-VL family is on the HIP path")
-        model = convert_qwen2_to_streaming(model)
+        if model_base not in ("Qwen2", "Qwen2_5"):
+            raise ValueError(f"model_base must be 'Qwen2' or 'Qwen2_5', not {model_base!r}")
+        model = (convert_qwen2_5_to_streaming if model_base == "Qwen2_5" else convert_qwen2_to_streaming)(model)
     device = model.device
 
     assistant_start_bias = len(processor(text="<|im_start|>assistant\n")["input_ids"][0])

@@ -24,7 +24,7 @@ import torch
 from ._lib import ACT_GELU_ERF, ACT_QUICK_GELU
 from .config import ModelConfig
 from .kv_pool import KVPool
-from .positions import rope_index_qwen2
+from .positions import rope_index_1d, rope_index_qwen2, rope_index_qwen2_5
 from .weights import EngineWeights
 
 BF16 = torch.bfloat16
@@ -36,6 +36,45 @@ class GenerateOutput:
     past_key_values: KVPool
     logits: Optional[List[torch.Tensor]] = None      # fp32 last-row logits per forward (tests)
     n_new: int = 0
+
+
+def _window_plan(grid, merge: int, window_size: int, patch: int):
+    """Window order of a Qwen2.5-VL tower (transformers.vision_utils.get_vision_window_index, the helper behind
+    Qwen2_5_VisionTransformerPretrainedModel.get_window_index that the reference calls at qwen2_5/vision_forward.py:65):
+    returns (window_index over merged tokens, window lengths in PATCHES, frame lengths in patches)."""
+    vw = window_size // merge // patch
+    unit = merge * merge
+    index, win_len, frame_len = [], [], []
+    base = 0
+    for t, h, w in grid:
+        gh, gw = h // merge, w // merge
+        idx = np.arange(t * gh * gw).reshape(t, gh, gw)
+        ph, pw = vw - gh % vw, vw - gw % vw                  # the helper pads a FULL window when the size divides evenly
+        padded = np.full((t, gh + ph, gw + pw), -100, dtype=np.int64)
+        padded[:, :gh, :gw] = idx
+        nh, nw = (gh + ph) // vw, (gw + pw) // vw
+        padded = padded.reshape(t, nh, vw, nw, vw).transpose(0, 1, 3, 2, 4).reshape(t, nh * nw, vw * vw)
+        for row in padded.reshape(-1, vw * vw):
+            keep = row[row != -100]
+            if keep.size:                                    # empty windows vanish (unique_consecutive on the cu_seqlens)
+                index.append(keep + base)
+                win_len.append(int(keep.size) * unit)
+        base += t * gh * gw
+        frame_len += [h * w] * t
+    return np.concatenate(index).astype(np.int32), win_len, frame_len
+
+
+def _runs(lengths):
+    """Consecutive equal lengths -> [(first row, count, length)]: each run is one svlm_vit_attn launch."""
+    out, row, i = [], 0, 0
+    while i < len(lengths):
+        j = i
+        while j < len(lengths) and lengths[j] == lengths[i]:
+            j += 1
+        out.append((row, j - i, lengths[i]))
+        row += (j - i) * lengths[i]
+        i = j
+    return out
 
 
 class _VitRun:
@@ -62,9 +101,44 @@ class _VitRun:
         self.h = torch.empty_like(self.x)
         self.qkv = torch.empty((N, 3 * E), dtype=BF16, device=eng.device)
         self.a = torch.empty((N, E), dtype=BF16, device=eng.device)
-        self.f = torch.empty((N, vc.mlp_hidden), dtype=BF16, device=eng.device)
+        self.q25 = vc.arch == "qwen2_5"
+        if self.q25:
+            # window order (qwen2_5/vision_forward.py:65-83): groups of merge^2 patches are gathered so that every
+            # attention window is one contiguous run of rows; the rotary tables follow the same permutation
+            plan = eng._vit_windows(grid)
+            m2 = vc.spatial_merge_size ** 2
+            self.x = o.gather_rows(self.x.view(N // m2, m2 * E), None, plan["index"],
+                                   torch.empty((N // m2, m2 * E), dtype=BF16, device=eng.device)).view(N, E)
+            self.cosT, self.sinT = plan["cos"], plan["sin"]
+            self.win_runs, self.full_runs, self.rev = plan["win_runs"], plan["full_runs"], plan["reverse"]
+            self.f = torch.empty((N, 2 * vc.mlp_padded), dtype=BF16, device=eng.device)
+            self.g = torch.empty((N, vc.mlp_padded), dtype=BF16, device=eng.device)
+        else:
+            self.f = torch.empty((N, vc.mlp_hidden), dtype=BF16, device=eng.device)
+
+    def _blocks_2_5(self, lo: int, hi: int):
+        """Qwen2_5_VLVisionBlock x (hi - lo): RMSNorm -> qkv -> 2-D rope -> window / full attention -> proj + residual ->
+        RMSNorm -> SwiGLU (gate|up fused, biases) -> down + residual (qwen2_5/vision_forward.py:6-50,89-92)."""
+        o, vc = self.eng.ops, self.eng.cfg.vision
+        Hh, d, E = vc.num_heads, vc.head_dim, vc.embed_dim
+        scale = 1.0 / math.sqrt(d)
+        x, h, qkv, a = self.x, self.h, self.qkv, self.a
+        for bi in range(lo, hi):
+            bw = self.eng.w.vit[bi]
+            o.rmsnorm(x, bw["n1w"], 1e-6, out=h)
+            o.gemm(h, bw["qkv_w"], bias=bw["qkv_b"], out=qkv)
+            o.vit_rope(qkv, self.cosT, self.sinT, Hh, d)
+            for row, n, ln in (self.full_runs if bi in vc.fullatt_block_indexes else self.win_runs):
+                o.vit_attn(qkv[row:row + n * ln], n, ln, Hh, d, scale, out=a[row:row + n * ln])
+            o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
+            o.rmsnorm(x, bw["n2w"], 1e-6, out=h)
+            o.gemm(h, bw["gu_w"], bias=bw["gu_b"], out=self.f)
+            o.silu_mul(self.f, out=self.g)
+            o.gemm(self.g, bw["down_w"], bias=bw["down_b"], residual=x, out=x)
 
     def blocks(self, lo: int, hi: int):
+        if self.q25:
+            return self._blocks_2_5(lo, hi)
         o, vc = self.eng.ops, self.eng.cfg.vision
         Hh, d = vc.num_heads, vc.head_dim
         scale = 1.0 / math.sqrt(d)
@@ -81,11 +155,17 @@ class _VitRun:
 
     def finish(self):
         o, vc, mg = self.eng.ops, self.eng.cfg.vision, self.eng.w.merger
-        o.layernorm(self.x, mg["ln_w"], mg["ln_b"], 1e-6, out=self.h)
+        if self.q25:
+            o.rmsnorm(self.x, mg["ln_w"], 1e-6, out=self.h)
+        else:
+            o.layernorm(self.x, mg["ln_w"], mg["ln_b"], 1e-6, out=self.h)
         m2 = vc.spatial_merge_size ** 2
         hm = self.h.view(self.N // m2, vc.embed_dim * m2)
         g1 = o.gemm(hm, mg["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
-        return o.gemm(g1, mg["w2"], bias=mg["b2"])
+        out = o.gemm(g1, mg["w2"], bias=mg["b2"])
+        if self.q25:           # back from window order to token order (qwen2_5/vision_forward.py:96-97)
+            out = o.gather_rows(out, None, self.rev, torch.empty_like(out))
+        return out
 
 
 class SvlmEngine:
@@ -119,6 +199,7 @@ class SvlmEngine:
         inv = 1.0 / (tc.rope_theta ** (torch.arange(0, tc.head_dim, 2, dtype=torch.float) / tc.head_dim))
         self.inv_freq = inv.to(dev)
         self.pos3_dev = torch.zeros((3, self.max_len), dtype=torch.int32, device=dev)
+        self.posf_dev = torch.zeros((3, self.max_len), dtype=torch.float32, device=dev) if cfg.family == "qwen2_5" else None
         self.rope_cs = torch.zeros((self.max_len, tc.head_dim), dtype=BF16, device=dev)
         # sampling / feedback state
         self.tok_buf = torch.zeros(self.max_new + 1, dtype=torch.int32, device=dev)
@@ -184,6 +265,22 @@ class SvlmEngine:
             self._vit_rope_cache[key] = (fr.cos().contiguous().to(self.device), fr.sin().contiguous().to(self.device))
         return self._vit_rope_cache[key]
 
+    def _vit_windows(self, grid):
+        """Per-grid window plan of the Qwen2.5 tower, cached: gather index, its inverse, permuted rotary tables and the
+        (first row, count, length) launch runs of the windowed and of the full-attention blocks."""
+        key = ("win",) + tuple(tuple(int(v) for v in g) for g in grid)
+        if key not in self._vit_rope_cache:
+            vc = self.cfg.vision
+            m2 = vc.spatial_merge_size ** 2
+            index, win_len, frame_len = _window_plan(key[1:], vc.spatial_merge_size, vc.window_size, vc.patch_size)
+            cosT, sinT = self._vit_rope(grid)
+            rows = (torch.from_numpy(index).long().unsqueeze(1) * m2 + torch.arange(m2)).reshape(-1).to(self.device)
+            dev_i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+            self._vit_rope_cache[key] = dict(index=dev_i32(index), reverse=dev_i32(np.argsort(index, kind="stable")),
+                                             cos=cosT[rows].contiguous(), sin=sinT[rows].contiguous(),
+                                             win_runs=_runs(win_len), full_runs=_runs(frame_len))
+        return self._vit_rope_cache[key]
+
     def vision_forward(self, pixel_values, grid_thw):
         """streaming_visual_encoder_forward: (N, C*T*P*P) patches -> (N / merge^2, hidden)."""
         run = _VitRun(self, pixel_values, grid_thw)
@@ -226,7 +323,7 @@ class SvlmEngine:
         run, pend[4] = pend[4], None
         main = torch.cuda.current_stream()
         main.wait_event(pend[2])                       # the side stream's blocks: long finished by now
-        for t in (run.x, run.h, run.qkv, run.a, run.f):
+        for t in (run.x, run.h, run.qkv, run.a, run.f) + ((run.g,) if run.q25 else ()):
             t.record_stream(main)                      # allocated on the side stream, used here
         depth = self.cfg.vision.depth
         run.blocks(depth - min(self.vit_tail, depth), depth)
@@ -333,7 +430,8 @@ class SvlmEngine:
     # ------------------------------------------------------------------ generate
     def generate(self, ids: Sequence[int], cache: Optional[KVPool], video_grid_thw, pixel_values=None, grid_thw=None,
                  max_new_tokens: int = 20, repetition_penalty: float = 1.05, do_sample: bool = False, temperature: float = 1.0,
-                 suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None) -> GenerateOutput:
+                 suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
+                 all_text: bool = False, second_per_grid_t: Optional[float] = None) -> GenerateOutput:
         """`next_vision=(pixel_values, grid_thw)` of the FOLLOWING chunk, when the caller already has its frames, is
         encoded on a side stream underneath this chunk's decode steps (see `vision_prefetch`)."""
         cfg, tc, o = self.cfg, self.cfg.text, self.ops
@@ -352,13 +450,28 @@ class SvlmEngine:
             raise MemoryError(f"sequence {L_ids}+{max_new_tokens} exceeds engine max_len {self.max_len}")
         dev = self.device
         # ---- shrink-mode positions for the whole (pruned) sequence + the tokens to be generated
-        pos, nxt = rope_index_qwen2(ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
         n_rows = L_ids + max_new_tokens
-        pos_full = np.empty((3, n_rows), dtype=np.int32)
-        pos_full[:, :L_ids] = pos
-        pos_full[:, L_ids:] = nxt + np.arange(max_new_tokens, dtype=np.int32)
-        self.pos3_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
-        o.mrope_table(self.pos3_dev, self.inv_freq, self.rope_cs, 0, n_rows, tc.mrope_section)
+        if cfg.family == "qwen2_5" and not all_text:
+            # float positions: the temporal axis of vision tokens advances by second_per_grid_t * tokens_per_second
+            # (qwen2_5/pos_emb.py:107-127; the reference pins second_per_grid_t to 2 / FPS)
+            spg = 2.0 / float(os.environ.get("QWENVL_FPS", "2.0")) if second_per_grid_t is None else float(second_per_grid_t)
+            pos, nxt = rope_index_qwen2_5(ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id,
+                                          cfg.vision_start_token_id, spg, cfg.vision.tokens_per_second)
+            pos_full = np.empty((3, n_rows), dtype=np.float32)
+            pos_full[:, :L_ids] = pos
+            pos_full[:, L_ids:] = np.float32(nxt) + np.arange(max_new_tokens, dtype=np.float32)
+            pos_dev = self.posf_dev
+        else:
+            if all_text:       # 1-D rope on all three axes (qwen2_5/model_forward.py:6-28,99)
+                pos, nxt = rope_index_1d(L_ids)
+            else:
+                pos, nxt = rope_index_qwen2(ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
+            pos_full = np.empty((3, n_rows), dtype=np.int32)
+            pos_full[:, :L_ids] = pos
+            pos_full[:, L_ids:] = nxt + np.arange(max_new_tokens, dtype=np.int32)
+            pos_dev = self.pos3_dev
+        pos_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
+        o.mrope_table(pos_dev, self.inv_freq, self.rope_cs, 0, n_rows, tc.mrope_section)
         cache.reserve(T + max_new_tokens)
         cache.sync_device()
         # ---- embeddings of the un-cached suffix (vision rows spliced in order)

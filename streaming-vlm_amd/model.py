@@ -58,7 +58,8 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
         g_all = g_all[:ids.count(eng.cfg.vision_start_token_id)]
     grids_all = _grid_list(g_all)
     out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
-                       repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision)
+                       repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision,
+                       all_text=bool(streaming_args.all_text))
     # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)
     if streaming_args.input_ids is not None:
         streaming_args.input_ids = torch.nn.functional.pad(streaming_args.input_ids, (0, out.n_new), "constant", 0)
@@ -79,6 +80,15 @@ class StreamingQwen2VL:
 
     def new_cache(self):
         return self._svlm_engine.new_cache()
+
+
+def convert_qwen2_5_to_streaming(model, ops=None, **engine_kw):
+    """Same entry point as the reference's qwen2_5/patch_model.py:18-38 for `Qwen2_5_VLForConditionalGeneration`
+    (the family of the released StreamingVLM checkpoint): windowed RMSNorm/SwiGLU vision tower, float temporal M-RoPE."""
+    model = convert_qwen2_to_streaming(model, ops=ops, **engine_kw)
+    if model._svlm_engine.cfg.family != "qwen2_5":
+        raise ValueError("convert_qwen2_5_to_streaming needs a Qwen2.5-VL model (use convert_qwen2_to_streaming)")
+    return model
 
 
 def convert_qwen2_to_streaming(model, ops=None, **engine_kw):

@@ -27,16 +27,18 @@ OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
 # ----------------------------------------------------------------------------- frames
-def synthetic_frame(stream: int, t: int, size: int = 448) -> torch.Tensor:
+def synthetic_frame(stream: int, t: int, size=448) -> torch.Tensor:
+    """`size`: side of a square frame, or (height, width)."""
     g = torch.Generator()
     g.manual_seed(1234 + 1000 * stream + t)
-    return torch.randint(0, 256, (3, size, size), generator=g, dtype=torch.uint8)
+    h, w = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    return torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
 
 
 class SyntheticVideo:
     """Stand-in for the decord reader: frames are addressed by index at `fps` frames per second."""
 
-    def __init__(self, size: int = 448, fps: float = 1.0, stream: int = 0):
+    def __init__(self, size=448, fps: float = 1.0, stream: int = 0):
         self.size, self.fps, self.stream = size, fps, stream
 
     def chunk(self, start_s: float, duration_s: float) -> torch.Tensor:
@@ -50,9 +52,8 @@ class SyntheticVideo:
         m = re.fullmatch(r"synthetic://(\d+)x(\d+)@([\d.]+)fps(?:\?stream=(\d+))?", path or "")
         if not m:
             return None
-        if m.group(1) != m.group(2):
-            raise ValueError("synthetic frames are square")
-        return cls(int(m.group(1)), float(m.group(3)), int(m.group(4) or 0))
+        w, h = int(m.group(1)), int(m.group(2))          # WxH, like a resolution string
+        return cls(w if w == h else (h, w), float(m.group(3)), int(m.group(4) or 0))
 
 
 def patchify(frames: torch.Tensor, patch: int = 14, temporal: int = 2, merge: int = 2, device=None):

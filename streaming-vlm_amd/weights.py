@@ -21,17 +21,31 @@ def state_dict_shapes(cfg: ModelConfig) -> Dict[str, tuple]:
     vc, tc = cfg.vision, cfg.text
     E, Hd = vc.embed_dim, tc.hidden_size
     sh = {V_PREFIX + "patch_embed.proj.weight": (E, vc.in_channels, vc.temporal_patch_size, vc.patch_size, vc.patch_size)}
-    for b in range(vc.depth):
-        p = f"{V_PREFIX}blocks.{b}."
-        sh.update({p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,),
-                   p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
-                   p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,),
-                   p + "mlp.fc1.weight": (vc.mlp_hidden, E), p + "mlp.fc1.bias": (vc.mlp_hidden,),
-                   p + "mlp.fc2.weight": (E, vc.mlp_hidden), p + "mlp.fc2.bias": (E,)})
     M = E * vc.spatial_merge_size ** 2
     m = V_PREFIX + "merger."
-    sh.update({m + "ln_q.weight": (E,), m + "ln_q.bias": (E,), m + "mlp.0.weight": (M, M), m + "mlp.0.bias": (M,),
-               m + "mlp.2.weight": (Hd, M), m + "mlp.2.bias": (Hd,)})
+    if vc.arch == "qwen2_5":
+        # Qwen2_5_VLVisionBlock: RMSNorm (no bias), SwiGLU MLP with biases; merger ln_q is an RMSNorm
+        I = vc.mlp_hidden
+        for b in range(vc.depth):
+            p = f"{V_PREFIX}blocks.{b}."
+            sh.update({p + "norm1.weight": (E,), p + "norm2.weight": (E,),
+                       p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
+                       p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,),
+                       p + "mlp.gate_proj.weight": (I, E), p + "mlp.gate_proj.bias": (I,),
+                       p + "mlp.up_proj.weight": (I, E), p + "mlp.up_proj.bias": (I,),
+                       p + "mlp.down_proj.weight": (E, I), p + "mlp.down_proj.bias": (E,)})
+        sh.update({m + "ln_q.weight": (E,), m + "mlp.0.weight": (M, M), m + "mlp.0.bias": (M,),
+                   m + "mlp.2.weight": (Hd, M), m + "mlp.2.bias": (Hd,)})
+    else:
+        for b in range(vc.depth):
+            p = f"{V_PREFIX}blocks.{b}."
+            sh.update({p + "norm1.weight": (E,), p + "norm1.bias": (E,), p + "norm2.weight": (E,), p + "norm2.bias": (E,),
+                       p + "attn.qkv.weight": (3 * E, E), p + "attn.qkv.bias": (3 * E,),
+                       p + "attn.proj.weight": (E, E), p + "attn.proj.bias": (E,),
+                       p + "mlp.fc1.weight": (vc.mlp_hidden, E), p + "mlp.fc1.bias": (vc.mlp_hidden,),
+                       p + "mlp.fc2.weight": (E, vc.mlp_hidden), p + "mlp.fc2.bias": (E,)})
+        sh.update({m + "ln_q.weight": (E,), m + "ln_q.bias": (E,), m + "mlp.0.weight": (M, M), m + "mlp.0.bias": (M,),
+                   m + "mlp.2.weight": (Hd, M), m + "mlp.2.bias": (Hd,)})
     sh[L_PREFIX + "embed_tokens.weight"] = (tc.vocab_size, Hd)
     qd, kd = tc.num_heads * tc.head_dim, tc.num_kv_heads * tc.head_dim
     for i in range(tc.num_layers):
@@ -82,16 +96,36 @@ class EngineWeights:
 
         self.patch_embed = dev(sd[V_PREFIX + "patch_embed.proj.weight"].reshape(vc.embed_dim, -1))
         self.vit = []
-        for b in range(vc.depth):
-            p = f"{V_PREFIX}blocks.{b}."
-            self.vit.append({k: dev(sd[p + n]) for k, n in [
-                ("n1w", "norm1.weight"), ("n1b", "norm1.bias"), ("n2w", "norm2.weight"), ("n2b", "norm2.bias"),
-                ("qkv_w", "attn.qkv.weight"), ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"),
-                ("proj_b", "attn.proj.bias"), ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"),
-                ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")]})
         m = V_PREFIX + "merger."
-        self.merger = {k: dev(sd[m + n]) for k, n in [("ln_w", "ln_q.weight"), ("ln_b", "ln_q.bias"), ("w0", "mlp.0.weight"),
-                                                       ("b0", "mlp.0.bias"), ("w2", "mlp.2.weight"), ("b2", "mlp.2.bias")]}
+        if vc.arch == "qwen2_5":
+            I, Ip, E = vc.mlp_hidden, vc.mlp_padded, vc.embed_dim
+            for b in range(vc.depth):
+                p = f"{V_PREFIX}blocks.{b}."
+                blk = {k: dev(sd[p + n]) for k, n in [
+                    ("n1w", "norm1.weight"), ("n2w", "norm2.weight"), ("qkv_w", "attn.qkv.weight"), ("qkv_b", "attn.qkv.bias"),
+                    ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"), ("down_b", "mlp.down_proj.bias")]}
+                # gate and up fused row-wise, each padded with zero rows to a multiple of 8 (3420 -> 3424): the pad columns of
+                # h = silu(0) * 0 are exactly 0 and meet zero columns of down_proj, so the result is unchanged bit for bit
+                gu_w = torch.zeros((2 * Ip, E), dtype=torch.bfloat16, device=device)
+                gu_b = torch.zeros(2 * Ip, dtype=torch.bfloat16, device=device)
+                gu_w[:I].copy_(sd[p + "mlp.gate_proj.weight"]); gu_w[Ip:Ip + I].copy_(sd[p + "mlp.up_proj.weight"])
+                gu_b[:I].copy_(sd[p + "mlp.gate_proj.bias"]); gu_b[Ip:Ip + I].copy_(sd[p + "mlp.up_proj.bias"])
+                down_w = torch.zeros((E, Ip), dtype=torch.bfloat16, device=device)
+                down_w[:, :I].copy_(sd[p + "mlp.down_proj.weight"])
+                blk.update(gu_w=gu_w, gu_b=gu_b, down_w=down_w)
+                self.vit.append(blk)
+            self.merger = {k: dev(sd[m + n]) for k, n in [("ln_w", "ln_q.weight"), ("w0", "mlp.0.weight"), ("b0", "mlp.0.bias"),
+                                                           ("w2", "mlp.2.weight"), ("b2", "mlp.2.bias")]}
+        else:
+            for b in range(vc.depth):
+                p = f"{V_PREFIX}blocks.{b}."
+                self.vit.append({k: dev(sd[p + n]) for k, n in [
+                    ("n1w", "norm1.weight"), ("n1b", "norm1.bias"), ("n2w", "norm2.weight"), ("n2b", "norm2.bias"),
+                    ("qkv_w", "attn.qkv.weight"), ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"),
+                    ("proj_b", "attn.proj.bias"), ("fc1_w", "mlp.fc1.weight"), ("fc1_b", "mlp.fc1.bias"),
+                    ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias")]})
+            self.merger = {k: dev(sd[m + n]) for k, n in [("ln_w", "ln_q.weight"), ("ln_b", "ln_q.bias"), ("w0", "mlp.0.weight"),
+                                                           ("b0", "mlp.0.bias"), ("w2", "mlp.2.weight"), ("b2", "mlp.2.bias")]}
         self.embed = dev(sd[L_PREFIX + "embed_tokens.weight"])
         self.lm_head = self.embed if tc.tie_word_embeddings else dev(sd["lm_head.weight"])
         self.final_norm = dev(sd[L_PREFIX + "norm.weight"])

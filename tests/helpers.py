@@ -9,7 +9,8 @@ from oracle import model as om
 import streaming_vlm_amd as S
 from streaming_vlm_amd import config as C
 
-_V_KEYS = ["depth", "embed_dim", "num_heads", "mlp_hidden", "patch_size", "temporal_patch_size", "spatial_merge_size", "in_channels"]
+_V_KEYS = ["depth", "embed_dim", "num_heads", "mlp_hidden", "patch_size", "temporal_patch_size", "spatial_merge_size", "in_channels",
+           "arch", "window_size", "fullatt_block_indexes", "out_hidden", "tokens_per_second"]
 _T_KEYS = ["hidden_size", "num_layers", "num_heads", "num_kv_heads", "head_dim", "intermediate_size", "vocab_size", "rms_eps",
            "rope_theta", "mrope_section", "tie_word_embeddings"]
 
@@ -50,8 +51,10 @@ def run_oracle_stream(cfg, sd, n_chunks, size=56, fps=1.0, policy="sink_window",
 def run_engine_stream(model, n_chunks, size=56, fps=1.0, policy="sink_window", sink=4, window=64, max_new=8, suppress_eos=True,
                       previous_text="hello world", **kw):
     trace, counts, ids_log = [], [], []
-    res = S.streaming_inference(model=model, processor=S.SyntheticProcessor(), video_path=f"synthetic://{size}x{size}@{fps:g}fps",
-                                model_base="Qwen2", duration=n_chunks, previous_text=previous_text, kv_policy=policy, sink=sink,
+    size_s = f"{size[1]}x{size[0]}" if isinstance(size, (tuple, list)) else f"{size}x{size}"      # (h, w) -> "WxH"
+    base = "Qwen2_5" if model._svlm_engine.cfg.family == "qwen2_5" else "Qwen2"
+    res = S.streaming_inference(model=model, processor=S.SyntheticProcessor(), video_path=f"synthetic://{size_s}@{fps:g}fps",
+                                model_base=base, duration=n_chunks, previous_text=previous_text, kv_policy=policy, sink=sink,
                                 window=window, do_sample=False, max_new_tokens=max_new, suppress_eos=suppress_eos, quiet=True,
                                 trace=trace, token_counts=counts, ids_log=ids_log, **kw)
     return res, trace, counts, ids_log

@@ -78,11 +78,11 @@ def _compare(cfg, sd, n_chunks, model, **kw):
     return diverged
 
 
-def _tiny_model(use_graph=True, **kw):
+def _tiny_model(use_graph=True, family="qwen2", **kw):
     import streaming_vlm_amd as S
     from streaming_vlm_amd import config as C
     from streaming_vlm_amd.weights import random_state_dict
-    cfg = C.tiny(**kw)
+    cfg = C.tiny_2_5(**kw) if family == "qwen2_5" else C.tiny(**kw)
     sd = random_state_dict(cfg, 0, "cpu")
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8, use_graph=use_graph)
     return cfg, sd, model
@@ -91,6 +91,20 @@ def _tiny_model(use_graph=True, **kw):
 def test_tiny_stream_sink_window():
     cfg, sd, model = _tiny_model()
     _compare(cfg, sd, 6, model)
+
+
+def test_tiny_qwen2_5_stream_sink_window_ragged_windows():
+    """Qwen2.5-VL family: windowed RMSNorm/SwiGLU tower (112x84 frames -> ragged attention windows), float temporal M-RoPE."""
+    cfg, sd, model = _tiny_model(family="qwen2_5")
+    _compare(cfg, sd, 6, model, size=(112, 84), window=96)
+
+
+def test_tiny_qwen2_5_stream_structural_and_all_text():
+    cfg, sd, model = _tiny_model(family="qwen2_5")
+    _compare(cfg, sd, 7, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+             previous_text="a b c d e f g h i j k l m n o p")
+    cfg, sd, model = _tiny_model(family="qwen2_5")
+    _compare(cfg, sd, 4, model, all_text=True)
 
 
 def test_tiny_stream_structural():
@@ -120,7 +134,7 @@ def test_golden_streams_eviction_trace_and_tokens():
     with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_streams.json")) as f:
         gold = json.load(f)
     for name, g in gold.items():
-        cfg, sd, model = _tiny_model()
+        cfg, sd, model = _tiny_model(family="qwen2_5" if g.get("model") == "tiny_2_5" else "qwen2")
         _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], **dict(g["kwargs"]))
         assert [[list(t) for t in c] for c in trace] == g["trace"], name
         assert [e["kv_len"] for e in ids_log] == g["kv_len"], name

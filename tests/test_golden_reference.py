@@ -96,3 +96,19 @@ def test_streaming_args_surface():
     assert a.pos_mode == "shrink" and a.all_text is False and a.input_ids is None and a.video_grid_thw is None
     with pytest.raises(AssertionError):
         S.StreamingArgs("nope")
+
+
+def test_all_text_positions_match_reference_1d_rope(golden_dir):
+    """StreamingArgs.all_text: vectors minted from the reference's importable get_1d_rope_index
+    (qwen2_5/model_forward.py:6-28) -- oracle restatement and product builder."""
+    import json, os
+    import numpy as np
+    from oracle.rope_index import get_1d_rope_index
+    from streaming_vlm_amd.positions import rope_index_1d
+    with open(os.path.join(golden_dir, "ref_rope_1d.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        want = np.array(g["pos"])
+        assert np.array_equal(get_1d_rope_index(g["n"]), want), name
+        pos, nxt = rope_index_1d(g["n"])
+        assert np.array_equal(pos, want) and nxt == g["n"] and g["delta"] == 0

@@ -29,11 +29,14 @@ def test_engine_equals_oracle_and_golden_traces(tiny, golden_dir):
     cfg, sd = tiny
     with open(os.path.join(golden_dir, "oracle_streams.json")) as f:
         gold = json.load(f)
+    cfg25 = C.tiny_2_5()
+    sd25 = random_state_dict(cfg25, 0, "cpu")
     for name, g in gold.items():
         if "default" in name:
             continue
         kw = dict(g["kwargs"])
-        res, trace, counts, log = H.run_engine_stream(_model(cfg, sd), g["n_chunks"], **kw)
+        model = _model(cfg25, sd25) if g.get("model") == "tiny_2_5" else _model(cfg, sd)       # Qwen2.5-VL family streams
+        res, trace, counts, log = H.run_engine_stream(model, g["n_chunks"], **kw)
         assert [[list(t) for t in c] for c in trace] == g["trace"], name          # identical eviction indices
         assert [e["kv_len"] for e in log] == g["kv_len"], name
         assert [e["new"] for e in log] == g["new_tokens"], name

@@ -82,3 +82,62 @@ def test_tiled_attention_equals_global_in_fp32():
     a = om.flash_attention(q, k, v, 143, 0.088)
     b = om._flash_attention_tiled(q, k, v, 143, 0.088, 32)
     assert torch.allclose(a, b, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- Qwen2.5-VL
+@pytest.fixture(scope="module")
+def hf25(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "hf_tiny_modules_2_5.npz")))
+
+
+@pytest.fixture(scope="module")
+def setup25():
+    cfg = C.tiny_2_5()
+    cfg.text.num_heads, cfg.text.num_kv_heads = 2, 1
+    return cfg, H.oracle_cfg(cfg), random_state_dict(cfg, 7, "cpu", dtype=torch.float32)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_qwen2_5_vision_tower(hf25, setup25, tag):
+    """Windowed RMSNorm/SwiGLU tower incl. ragged windows ((2,8,6) grid, 56-px windows) and two videos in one call,
+    against the stock Qwen2_5_VisionTransformerPretrainedModel."""
+    cfg, ocfg, sd = setup25
+    out = om.vit_forward(sd, ocfg, torch.from_numpy(hf25[f"vit_pix_{tag}"]), hf25[f"vit_grid_{tag}"].tolist())
+    want = torch.from_numpy(hf25[f"vit_out_{tag}"])
+    err = float((out - want).abs().max())
+    print("qwen2.5 vit max abs err", err)
+    assert out.shape == want.shape and err < 2e-4 * float(want.abs().max()) + 1e-5
+
+
+@pytest.mark.parametrize("tag,spg", [("1", 1.0), ("h", 0.5)])
+def test_qwen2_5_rope_index(hf25, setup25, tag, spg):
+    """Float temporal M-RoPE ids: oracle restatement and the product's vectorised builder against the stock
+    Qwen2_5_VLModel.get_rope_index (second_per_grid_ts 1.0 and 0.5, tokens_per_second 2)."""
+    from oracle.rope_index import get_rope_index_2_5
+    from streaming_vlm_amd.positions import rope_index_qwen2_5
+    cfg, ocfg, sd = setup25
+    ids, grids = hf25["rope_ids"].tolist(), hf25["rope_grids"].tolist()
+    want = hf25[f"rope_pos_{tag}"]
+    got_o = get_rope_index_2_5(ids, grids, 2, cfg.video_token_id, cfg.vision_start_token_id, spg, 2.0)
+    got_p, nxt = rope_index_qwen2_5(ids, grids, 2, cfg.video_token_id, cfg.vision_start_token_id, spg, 2.0)
+    assert np.array_equal(got_p, got_o) and nxt == float(got_o.max()) + 1       # product == line-by-line restatement
+    if spg == 1.0:
+        assert np.array_equal(got_o, want), (got_o[0], want[0])
+    else:
+        # the stock module truncates the temporal index to integers; the reference REPLACES it with its own float32
+        # version (qwen2_5/pos_emb.py:121-126, bound at patch_model.py:37), which the restatement follows: only the temporal
+        # axis of the second grid step may differ from the stock vector, and only by the truncated fraction
+        diff = np.flatnonzero((got_o != want).any(0))
+        assert set(diff.tolist()) <= set(range(32, 44)) and np.array_equal(got_o[1:], want[1:])
+
+
+def test_qwen2_5_window_plan_matches_oracle():
+    """The engine's numpy window plan == the oracle's restatement of get_window_index for divisible, ragged and
+    multi-video grids."""
+    from streaming_vlm_amd.engine import _window_plan
+    for grid, ws in (([[1, 32, 32]], 112), ([[2, 8, 6]], 56), ([[1, 4, 4], [3, 10, 14]], 56), ([[1, 36, 20]], 112)):
+        idx, cu = om.get_window_index(grid, 2, ws, 14)
+        index, win_len, frame_len = _window_plan([tuple(g) for g in grid], 2, ws, 14)
+        assert np.array_equal(index, idx.numpy())
+        assert np.cumsum([0] + win_len).tolist() == cu
+        assert sum(frame_len) == sum(t * h * w for t, h, w in grid)
