@@ -59,7 +59,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     import streaming_vlm_amd as S
     from streaming_vlm_amd import multi_stream as MS
-    dist, rank, world, local_rank = MS.init_distributed("nccl")          # nccl == RCCL over xGMI on ROCm
+    # nccl == RCCL over xGMI on ROCm.  SVLM_DIST_BACKEND=gloo is the rehearsal mode for a box with fewer GPUs than ranks
+    # (ranks then share cards; RCCL needs one device per rank): same barriers, same aggregation, host-side collectives.
+    backend = os.environ.get("SVLM_DIST_BACKEND", "nccl")
+    dist, rank, world, local_rank = MS.init_distributed(backend)
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -119,7 +124,7 @@ def main():
     log(f"timed region done: {elapsed:.3f} s for {args.steps} chunks")
     frames = args.steps * frames_per_chunk
     tokens = sum(counts[args.warmup:])
-    agg = MS.aggregate(frames, tokens, elapsed, dist, dev)
+    agg = MS.aggregate(frames, tokens, elapsed, dist, dev if backend == "nccl" else "cpu")
     t_max, fps_total, tps_total, per_gpu_fps = agg["t_max"], agg["frames_per_sec"], agg["tokens_per_sec"], agg["per_rank_frames_per_sec"]
 
     out = {
