@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #define GLDS(gp, lp) \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp), (__attribute__((address_space(3))) void*)(lp), 16, 0, 0)
 
-template <int TM>
+// GEMM_DIAG (compile-time, tools only): 1 = K loop without the DMA issue (LDS reads + MFMA + barrier only),
+// 2 = K loop without the compute (DMA + waits + barrier only) -- splits the per-K-step cost into its two halves.
+#ifndef GEMM_DIAG
+#define GEMM_DIAG 0
+#endif
+template <int TM, int NS>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         const bf16_t* __restrict__ bias,
@@ -277,21 +282,35 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
     }
   };
 
-  // prologue: two tiles in flight
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  // NS-stage ring, NS-1 tiles in flight.  Measured with the GEMM_DIAG builds (tools/gemm_shapes.py, ViT qkv 1024x3840x1280): whole
+  // kernel 24.6 us, K loop WITHOUT any MFMA 24.1 us, WITHOUT the DMA 18.4 us -- the loop is bound by the L2/fabric -> LDS stream
+  // (157 MB per GEMM at 128x128 tiles), not by MFMA or LDS reads.  A 4-stage ring (3 tiles in flight) made it SLOWER (31.0 us):
+  // more bytes in flight do not help a bandwidth-bound stream and cost the second resident workgroup at BM = 64.  NS = 3.
+  constexpr int AHEAD = NS - 1;
+#pragma unroll
+  for (int t = 0; t < AHEAD; ++t)
+    if (t < nk) issue(t, t);
+#if GEMM_DIAG == 1
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt landed when at most the NEWER tile's NPT pieces are outstanding; then everyone passed compute(kt-1),
-    // whose stage ((kt+2) % 3) may be refilled
-    if (kt + 1 < nk) {
-      if constexpr (NPT == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-    compute(kt % 3);
+    asm volatile("s_barrier" ::: "memory");
+    compute(kt % 2);
   }
+#else
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed when at most the NEWER tiles' pieces are outstanding (min(AHEAD - 1, nk - 1 - kt) tiles of NPT pieces);
+    // after the barrier everyone has passed compute(kt-1), whose stage (kt + AHEAD) % NS may be refilled
+    const int newer = min(AHEAD - 1, nk - 1 - kt);
+    if (newer >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * NPT) : "memory");
+    else if (newer == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NPT) : "memory");
+    else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NS);
+#if GEMM_DIAG != 2
+    compute(kt % NS);
+#endif
+  }
+#endif
 
   // epilogue: lane holds m = fr (column of D), n = 4*fq + r (rows of D)
 #pragma unroll
@@ -420,11 +439,13 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
   }
   const bool dma = (K % GEMM_BK == 0) && getenv("SVLM_GEMM_NO_DMA") == nullptr;
   if (dma) {
-    constexpr int DLDS2 = 3 * (64 + GEMM_BN) * 128, DLDS4 = 3 * (128 + GEMM_BN) * 128;
+    // ring depth: 3 stages (72 KB at BM = 64: two workgroups per CU; 96 KB at BM = 128); 4 measured slower, see the kernel
+    constexpr int NS2 = 3, NS4 = 3;
+    constexpr int DLDS2 = NS2 * (64 + GEMM_BN) * 128, DLDS4 = NS4 * (128 + GEMM_BN) * 128;
     static bool dma_attr_done = false;
     if (!dma_attr_done) {
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS2);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS4);
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<2, NS2>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS2);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<4, NS4>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS4);
       if (e1 != hipSuccess || e2 != hipSuccess) {
         svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", DLDS4, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         return SVLM_ELAUNCH;
@@ -432,10 +453,10 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
       dma_attr_done = true;
     }
     if (small) {
-      gemm_glds_kernel<2><<<grid, 256, DLDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+      gemm_glds_kernel<2, NS2><<<grid, 256, DLDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
     } else {
-      gemm_glds_kernel<4><<<grid, 256, DLDS4, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+      gemm_glds_kernel<4, NS4><<<grid, 256, DLDS4, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
     }
   } else if (small) {

@@ -187,11 +187,6 @@ class SvlmEngine:
             decode_chunk = self.pick_decode_chunk(self.max_len, tc.num_kv_heads)
         self.decode_chunk = int(os.environ.get("SVLM_DECODE_CHUNK", decode_chunk))
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
-        # EXPERIMENT, off by default: Infinity-Cache prefetch of layer l+1's weights on a side stream while layer l computes.
-        # Measured on MI355X (2B, round 1): 52.7 ms/chunk with it vs 38.2 without -- the 27 fork/joins per step and the
-        # contention with the foreground GEMVs cost more than the warm lines save.  Kept for the persistent-kernel work.
-        self.prefetch = os.environ.get("SVLM_PREFETCH", "0") == "1" and self.device.type == "cuda"
-        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
         dev = self.device
         H, V = tc.hidden_size, tc.vocab_size
         self.qd, self.kd = tc.num_heads * tc.head_dim, tc.num_kv_heads * tc.head_dim
@@ -387,12 +382,7 @@ class SvlmEngine:
         kv_len = self.state[0:1]
         scale = 1.0 / math.sqrt(tc.head_dim)
         o.gather_rows(w.embed, None, self.tok_buf, self.d_x.view(1, H), idx_off=self.state[1:2])
-        main = torch.cuda.current_stream() if self.prefetch else None
         for li, lw in enumerate(w.layers):
-            if self.prefetch and li + 1 < len(w.layers):
-                self._side.wait_stream(main)                       # fork: starts when layer li starts
-                with torch.cuda.stream(self._side):
-                    o.prefetch(w.layers[li + 1]["flat"])
             o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
                       len_dev=kv_len)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
@@ -400,8 +390,6 @@ class SvlmEngine:
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
             o.dec_gate_up(self.d_x, lw["ln2"], tc.rms_eps, lw["gu_w"], self.d_h)
             o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)
-        if self.prefetch:
-            main.wait_stream(self._side)                           # join (required to close a graph capture)
         o.dec_lm_head(self.d_x, w.final_norm, tc.rms_eps, w.lm_head, self.logits, self.seen if self._penalty != 1.0 else None,
                       self._penalty, self._suppress, self.d_sws)
 
