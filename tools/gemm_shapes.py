@@ -22,8 +22,10 @@ for name, M, N, K, has_bias, has_res in shapes:
     if only and only not in name:
         continue
     nW = 28
-    Ws = [r(N, K) for _ in range(nW)]
-    A, C = r(M, K), torch.empty(M, N, dtype=bf, device="cuda")
+    # PAD_W / PAD_A (elements): leading-dimension padding, to see whether power-of-two-ish row strides cost L2 channel conflicts
+    pw, pa = int(os.environ.get("PAD_W", 0)), int(os.environ.get("PAD_A", 0))
+    Ws = [r(N, K + pw)[:, :K] for _ in range(nW)]
+    A, C = r(M, K + pa)[:, :K], torch.empty(M, N, dtype=bf, device="cuda")
     bias = r(N) if has_bias else None
     res = r(M, N) if has_res else None
     fn = lambda: [o.gemm(A, W, bias=bias, residual=res, out=C) for W in Ws]
