@@ -45,8 +45,20 @@ class GenOut:
 def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=None, grid_thw=None,
              max_new_tokens=20, rep_penalty=1.05, eos_ids=(151645, 151643), suppress_eos=False,
              do_sample=False, temperature=1.0, generator: Optional[torch.Generator] = None,
-             keep_logits=False, all_text=False, second_per_grid_t=1.0) -> GenOut:
-    """One ``model.generate(**inputs, past_key_values=kv, streaming_args=...)`` call."""
+             keep_logits=False, all_text=False, second_per_grid_t=1.0, pos_mode="shrink", sargs: Optional[dict] = None) -> GenOut:
+    """One ``model.generate(**inputs, past_key_values=kv, streaming_args=...)`` call.  `sargs` is the part of StreamingArgs
+    that outlives a call: {"last_cache_position": int} (streaming_args.py:9, used by pos_mode="append")."""
+    if sargs is None:
+        sargs = {"last_cache_position": -1}
+
+    def index(seq, grids):
+        if all_text:                                                        # qwen2_5/model_forward.py:99
+            return get_1d_rope_index(len(seq))
+        if cfg.vision.arch == "qwen2_5":                                    # qwen2_5/model_forward.py:101-110
+            return get_rope_index_2_5(seq, grids, cfg.vision.spatial_merge_size, cfg.video_token_id,
+                                      cfg.vision_start_token_id, second_per_grid_t, cfg.vision.tokens_per_second)
+        return get_rope_index(seq, grids, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
+
     ids = list(ids)
     sa_ids = list(ids)                       # streaming_args.input_ids (padded with 0 per forward)
     out_logits = []
@@ -55,18 +67,21 @@ def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=
     while True:
         kv_len = kv.get_seq_length()
         new_ids = ids[kv_len:]                                              # prepare_generation.py:31-35
-        if all_text:                                                        # qwen2_5/model_forward.py:99
-            pos3 = get_1d_rope_index(len(sa_ids))
-        elif cfg.vision.arch == "qwen2_5":                                  # qwen2_5/model_forward.py:101-110
-            pos3 = get_rope_index_2_5(sa_ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id,
-                                      cfg.vision_start_token_id, second_per_grid_t, cfg.vision.tokens_per_second)
-        else:
-            pos3 = get_rope_index(sa_ids, video_grid_thw, cfg.vision.spatial_merge_size,
-                                  cfg.video_token_id, cfg.vision_start_token_id)   # model_forward.py:119-126
+        if pos_mode == "shrink":                                            # model_forward.py:119-126
+            pos3 = index(sa_ids, video_grid_thw)
+        elif kv_len == 0:                                                   # append, branch 1 (:77-90)
+            pos3 = index(new_ids, grid_thw if grid_thw is not None else video_grid_thw)
+        elif len(new_ids) != 1:                                             # append, chunk prefill (:91-99)
+            pos3 = index(new_ids, grid_thw if grid_thw is not None else []) + (sargs["last_cache_position"] + 1)
+        else:                                                               # append, decode (:100-114)
+            import numpy as _np
+            pos3 = _np.full((3, 1), sargs["last_cache_position"] + 1, dtype=_np.float32 if cfg.vision.arch == "qwen2_5" else _np.int64)
+        if pos_mode == "append":
+            sargs["last_cache_position"] = pos3[0, -1].item()               # :117
         has_vid = cfg.video_token_id in new_ids
         logits = model_forward(w, cfg, new_ids, kv, pos3,
                                pixel_values if (first and has_vid) else None,
-                               grid_thw if (first and has_vid) else None)
+                               grid_thw if (first and has_vid) else None, pos_mode=pos_mode)
         first = False
         sa_ids = sa_ids + [0]                                               # language_forward.py:323-325
         raw = logits[-1].float()                                            # streaming_generate_qwen.py:73
@@ -105,6 +120,7 @@ class StreamCfg:
     assistant_end_bias: int = 2           # len(tok(" ...<|im_end|>"))           inference.py:229
     all_text: bool = False                # StreamingArgs.all_text: 1-D rope (qwen2_5/model_forward.py:99)
     second_per_grid_t: float = 1.0        # 2 / FPS (qwen2_5/pos_emb.py:107-108)
+    pos_mode: str = "shrink"              # StreamingArgs.pos_mode (streaming_args.py:2-6)
 
 
 def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
@@ -116,6 +132,7 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
     """
     kv = kv_policy.ListKV(cfg.text.num_layers)
     prev_ids: Optional[List[int]] = None
+    sargs = {"last_cache_position": -1}                                     # StreamingArgs lives for the whole stream (inference.py:213)
     grids: List[List[int]] = []
     trace, new_tokens, kv_lens, all_logits, ids_hist = [], [], [], [], []
     for i in range(n_chunks):
@@ -142,7 +159,7 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
         cur_len = len(ids)
         out = generate(w, cfg, ids, kv, grids, pix, grid, scfg.max_new_tokens, scfg.repetition_penalty,
                        suppress_eos=scfg.suppress_eos, keep_logits=keep_logits, all_text=scfg.all_text,
-                       second_per_grid_t=scfg.second_per_grid_t)
+                       second_per_grid_t=scfg.second_per_grid_t, pos_mode=scfg.pos_mode, sargs=sargs)
         gen = out.sequences
         if gen[-1] != qr.IM_END:                                            # :457-459
             gen = gen + [qr.IM_END]

@@ -247,6 +247,10 @@ def gen_oracle_vectors():
         "structural_default_16": dict(policy="structural", text_round=16, window_size=16, text_sink=512, text_sliding_window=512),
         # BASELINE configs[0] geometry: 32 frames of 224x224 (64 vision tokens each), sink 4 / window 256, greedy, rep-pen 1.05
         "cfg0_224_sink4_win256_32": dict(policy="sink_window", sink=4, window=256, size=224),
+        # pos_mode="append": positions travel with their rows (rotated-K cache in the reference), nothing is re-indexed
+        "append_sink4_win64": dict(policy="sink_window", sink=4, window=64, pos_mode="append"),
+        "append_structural_t2_v3": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+                                        previous_text="a b c d e f g h i j k l m n o p", pos_mode="append"),
     }.items():
         n = 20 if "default" in name else (32 if name.startswith("cfg0") else 10)
         o = H.run_oracle_stream(cfg, sd, n, **kw)
@@ -260,6 +264,8 @@ def gen_oracle_vectors():
         "q25_structural_t2_v3": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
                                      previous_text="a b c d e f g h i j k l m n o p"),
         "q25_all_text": dict(policy="sink_window", sink=4, window=64, all_text=True),
+        "q25_append_structural": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+                                      previous_text="a b c d e f g h i j k l m n o p", pos_mode="append"),
     }.items():
         o = H.run_oracle_stream(cfg25, sd25, 10, **kw)
         runs[name] = {"model": "tiny_2_5", "kwargs": kw, "n_chunks": 10, "trace": o["trace"], "kv_len": o["kv_len"],

@@ -299,16 +299,19 @@ def apply_rope(x, cos, sin):
     return (x * cos.unsqueeze(0)) + (rotate_half(x) * sin.unsqueeze(0))
 
 
-def decoder_forward(w: dict, cfg: ModelCfg, x, kv, pos3, prefix="model.language_model."):
-    """streaming_language_model_forward in shrink mode (language_forward.py:212-334).
+def decoder_forward(w: dict, cfg: ModelCfg, x, kv, pos3, prefix="model.language_model.", pos_mode="shrink"):
+    """streaming_language_model_forward (language_forward.py:212-334).
 
     x     (T, H) input embeddings of the un-cached suffix
-    kv    ListKV holding UN-ROTATED keys (language_forward.py:95-97)
-    pos3  (3, L+T) position ids of the WHOLE sequence (model_forward.py:119-126)
+    shrink: kv holds UN-ROTATED keys (language_forward.py:95-97), pos3 (3, L+T) are the position ids of the WHOLE sequence
+            (model_forward.py:119-126), q and all keys are rotated AFTER the cache update (:99-103)
+    append: pos3 (3, T) are the positions of the new rows only (model_forward.py:75-117); q and the new keys are rotated
+            BEFORE the cache update (:89-93), so kv holds ROTATED keys that are never touched again
     Returns final-norm hidden (T, H).
     """
     tc = cfg.text
     T = x.shape[0]
+    append = pos_mode == "append"
     cos, sin = mrope_cos_sin(pos3, tc.head_dim, tc.rope_theta, tc.mrope_section, x.dtype)
     G = tc.num_heads // tc.num_kv_heads
     scale = 1.0 / math.sqrt(tc.head_dim)
@@ -322,12 +325,19 @@ def decoder_forward(w: dict, cfg: ModelCfg, x, kv, pos3, prefix="model.language_
         q = q.view(T, tc.num_heads, tc.head_dim).transpose(0, 1)            # (Hq, T, D)
         k = k.view(T, tc.num_kv_heads, tc.head_dim).transpose(0, 1).unsqueeze(0)
         v = v.view(T, tc.num_kv_heads, tc.head_dim).transpose(0, 1).unsqueeze(0)
-        K, V = kv.update(k, v, li)                                          # un-rotated append
+        if append:
+            assert cos.shape[0] == T, (cos.shape, T)
+            qr_ = apply_rope(q, cos, sin)
+            k = apply_rope(k[0], cos, sin).unsqueeze(0)                     # rotated BEFORE caching (:89-93)
+        K, V = kv.update(k, v, li)
         K, V = K[0], V[0]                                                   # (Hkv, L, D)
         L = K.shape[1]
-        assert cos.shape[0] == L, (cos.shape, L)
-        qr_ = apply_rope(q, cos[-T:], sin[-T:])                             # right-aligned (:44-53)
-        Kr = apply_rope(K, cos, sin)                                        # ALL cached keys (:55-63)
+        if append:
+            Kr = K
+        else:
+            assert cos.shape[0] == L, (cos.shape, L)
+            qr_ = apply_rope(q, cos[-T:], sin[-T:])                         # right-aligned (:44-53)
+            Kr = apply_rope(K, cos, sin)                                    # ALL cached keys (:55-63)
         Kr = Kr.repeat_interleave(G, dim=0)
         Vr = V.repeat_interleave(G, dim=0)
         a = flash_attention(qr_, Kr, Vr, L - T, scale)                      # causal, bottom-right aligned
@@ -346,7 +356,7 @@ def lm_head_weight(w):
 
 
 def model_forward(w: dict, cfg: ModelCfg, new_ids, kv, pos3, pixel_values=None, grid_thw=None,
-                  all_rows: bool = False):
+                  all_rows: bool = False, pos_mode: str = "shrink"):
     """qwen2_vl_forward / model_forward (qwen2/model_forward.py:6-150,195-256) on the
     un-cached suffix `new_ids`.  Returns logits (rows, V) in the model dtype; the
     reference computes all T rows (:243) and consumes only the last one
@@ -360,7 +370,7 @@ def model_forward(w: dict, cfg: ModelCfg, new_ids, kv, pos3, pixel_values=None, 
             raise ValueError(f"Video features and video tokens do not match: tokens: {int(mask.sum())}, features {ve.shape[0]}")
         x = x.clone()
         x[mask] = ve.to(x.dtype)                                             # masked_scatter, row order
-    h = decoder_forward(w, cfg, x, kv, pos3)
+    h = decoder_forward(w, cfg, x, kv, pos3, pos_mode=pos_mode)
     if not all_rows:
         h = h[-1:]
     return F.linear(h, lm_head_weight(w))

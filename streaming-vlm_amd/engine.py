@@ -419,7 +419,8 @@ class SvlmEngine:
     def generate(self, ids: Sequence[int], cache: Optional[KVPool], video_grid_thw, pixel_values=None, grid_thw=None,
                  max_new_tokens: int = 20, repetition_penalty: float = 1.05, do_sample: bool = False, temperature: float = 1.0,
                  suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
-                 all_text: bool = False, second_per_grid_t: Optional[float] = None) -> GenerateOutput:
+                 all_text: bool = False, second_per_grid_t: Optional[float] = None, pos_mode: str = "shrink",
+                 last_cache_position: float = -1) -> GenerateOutput:
         """`next_vision=(pixel_values, grid_thw)` of the FOLLOWING chunk, when the caller already has its frames, is
         encoded on a side stream underneath this chunk's decode steps (see `vision_prefetch`)."""
         cfg, tc, o = self.cfg, self.cfg.text, self.ops
@@ -439,25 +440,41 @@ class SvlmEngine:
         dev = self.device
         # ---- shrink-mode positions for the whole (pruned) sequence + the tokens to be generated
         n_rows = L_ids + max_new_tokens
-        if cfg.family == "qwen2_5" and not all_text:
-            # float positions: the temporal axis of vision tokens advances by second_per_grid_t * tokens_per_second
-            # (qwen2_5/pos_emb.py:107-127; the reference pins second_per_grid_t to 2 / FPS)
-            spg = 2.0 / float(os.environ.get("QWENVL_FPS", "2.0")) if second_per_grid_t is None else float(second_per_grid_t)
-            pos, nxt = rope_index_qwen2_5(ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id,
-                                          cfg.vision_start_token_id, spg, cfg.vision.tokens_per_second)
-            pos_full = np.empty((3, n_rows), dtype=np.float32)
-            pos_full[:, :L_ids] = pos
-            pos_full[:, L_ids:] = np.float32(nxt) + np.arange(max_new_tokens, dtype=np.float32)
-            pos_dev = self.posf_dev
-        else:
+        is_f = cfg.family == "qwen2_5" and not all_text
+        spg = 2.0 / float(os.environ.get("QWENVL_FPS", "2.0")) if second_per_grid_t is None else float(second_per_grid_t)
+
+        def index(seq, grids):
+            """(3, len) positions of a self-contained id sequence + the position after it."""
             if all_text:       # 1-D rope on all three axes (qwen2_5/model_forward.py:6-28,99)
-                pos, nxt = rope_index_1d(L_ids)
-            else:
-                pos, nxt = rope_index_qwen2(ids, video_grid_thw, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
-            pos_full = np.empty((3, n_rows), dtype=np.int32)
+                return rope_index_1d(len(seq))
+            if is_f:           # float temporal axis: second_per_grid_t * tokens_per_second per grid step (qwen2_5/pos_emb.py:107-127)
+                return rope_index_qwen2_5(seq, grids, cfg.vision.spatial_merge_size, cfg.video_token_id,
+                                          cfg.vision_start_token_id, spg, cfg.vision.tokens_per_second)
+            return rope_index_qwen2(seq, grids, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
+
+        pos_full = np.empty((3, n_rows), dtype=np.float32 if is_f else np.int32)
+        if pos_mode == "shrink":
+            # positions re-derived from the pruned ids on every chunk (qwen2/model_forward.py:119-126)
+            pos, nxt = index(ids, video_grid_thw)
             pos_full[:, :L_ids] = pos
-            pos_full[:, L_ids:] = nxt + np.arange(max_new_tokens, dtype=np.int32)
-            pos_dev = self.pos3_dev
+        elif pos_mode == "append":
+            # positions are assigned once and travel with their rows (qwen2/model_forward.py:75-117): the un-cached suffix is
+            # indexed on its own with THIS call's grids and shifted behind the last forwarded position; cached rows keep
+            # theirs (the reference caches rotated keys; un-rotated keys + their original positions give the same bits)
+            if L_before == 0:
+                pos, nxt = index(ids, grid_thw if grid_thw is not None else video_grid_thw)
+            else:
+                pos, nxt = index(ids[L_before:], grid_thw if grid_thw is not None else [])
+                off = last_cache_position + 1
+                pos = pos + (np.float32(off) if is_f else int(off))
+                pos_full[:, :L_before] = cache.pos_rows[:, :L_before]
+            pos_full[:, L_before:L_ids] = pos
+            # decode tokens continue on the TEMPORAL axis of the last forwarded token (:113-117)
+            nxt = float(pos[0, -1]) + 1
+        else:
+            raise ValueError(f"pos_mode must be 'shrink' or 'append', not {pos_mode!r}")
+        pos_full[:, L_ids:] = (np.float32(nxt) if is_f else int(nxt)) + np.arange(max_new_tokens, dtype=pos_full.dtype)
+        pos_dev = self.posf_dev if is_f else self.pos3_dev
         pos_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
         o.mrope_table(pos_dev, self.inv_freq, self.rope_cs, 0, n_rows, tc.mrope_section)
         cache.reserve(T + max_new_tokens)
@@ -493,7 +510,7 @@ class SvlmEngine:
         if do_sample:
             if next_vision is not None:
                 self.vision_prefetch(*next_vision)
-            return self._generate_sampling(ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out)
+            return self._generate_sampling(ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out, L_before, pos_full)
         self._sample_launch(0)
         if next_vision is not None:
             self.vision_prefetch(*next_vision)
@@ -518,10 +535,12 @@ class SvlmEngine:
                 break
         cache.commit(L_ids + n_new - 1)
         cache.release_reserved()
+        cache.pos_rows[:, L_before:cache.length] = pos_full[:, L_before:cache.length]
+        self.last_position = float(pos_full[0, cache.length - 1])           # streaming_args.last_cache_position
         seq = ids.tolist() + [int(t) for t in toks[:n_new]]
         return GenerateOutput(seq, cache, logits_out, n_new)
 
-    def _generate_sampling(self, ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out):
+    def _generate_sampling(self, ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out, L_before, pos_full):
         """do_sample=True (the reference's default: T=0.9, multinomial, streaming_generate_qwen.py:95-97).
         Token choice runs through torch on the device (RNG plumbing); forwards are the same kernels."""
         cfg = self.cfg
@@ -547,4 +566,6 @@ class SvlmEngine:
                 logits_out.append(self.logits.detach().cpu().clone())
         cache.commit(L_ids + len(new) - 1)
         cache.release_reserved()
+        cache.pos_rows[:, L_before:cache.length] = pos_full[:, L_before:cache.length]
+        self.last_position = float(pos_full[0, cache.length - 1])
         return GenerateOutput(ids.tolist() + new, cache, logits_out, len(new))

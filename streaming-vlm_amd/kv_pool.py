@@ -64,6 +64,9 @@ class KVPool:
         self._dirty_from = 0
         self.stats = dict(moved_rows=0, defrags=0, evicted_rows=0)
         self.key_cache, self.value_cache = _LayerPlanes(self, 0), _LayerPlanes(self, 1)
+        # pos_mode="append": the M-RoPE position of every cached row, edited in lockstep with slot_of (float64 holds the
+        # int positions of Qwen2-VL and the float32 ones of Qwen2.5-VL exactly)
+        self.pos_rows = np.zeros((3, self.max_len), dtype=np.float64)
         self._half = {}           # layer -> (which, rows): one plane assigned, waiting for its partner
         self._upd_rows = 0        # rows of an update() pass that has not reached the last layer yet
 
@@ -123,6 +126,7 @@ class KVPool:
             self._free_slot(int(s))
         n = end - start + 1
         self.slot_of[start:self.length - n] = self.slot_of[end + 1:self.length].copy()
+        self.pos_rows[:, start:self.length - n] = self.pos_rows[:, end + 1:self.length].copy()
         self.length -= n
         self.reserved = self.length
         self._dirty_from = min(self._dirty_from, start)
@@ -137,6 +141,10 @@ class KVPool:
         mid = so[dst + 1:src_s].copy()
         so[dst + 1:dst + 1 + seg.size] = seg
         so[dst + 1 + seg.size:src_e + 1] = mid
+        pr = self.pos_rows
+        pseg, pmid = pr[:, src_s:src_e + 1].copy(), pr[:, dst + 1:src_s].copy()
+        pr[:, dst + 1:dst + 1 + seg.size] = pseg
+        pr[:, dst + 1 + seg.size:src_e + 1] = pmid
         self._dirty_from = min(self._dirty_from, dst + 1)
 
     def truncate(self, new_length: int):

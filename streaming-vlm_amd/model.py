@@ -45,8 +45,6 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     eng: SvlmEngine = self._svlm_engine
     if streaming_args is None:
         raise ValueError("streaming_args is required (reference: every forward reads streaming_args.pos_mode)")
-    if streaming_args.pos_mode != "shrink":
-        raise NotImplementedError("pos_mode='append' (rotated-K cache, unbounded positions) is not part of the HIP path yet")
     if input_ids.shape[0] != 1:
         raise ValueError("the streaming loop is batch-1")
     ids = input_ids[0].tolist()
@@ -59,7 +57,9 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     grids_all = _grid_list(g_all)
     out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
                        repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision,
-                       all_text=bool(streaming_args.all_text))
+                       all_text=bool(streaming_args.all_text), pos_mode=streaming_args.pos_mode,
+                       last_cache_position=streaming_args.last_cache_position)
+    streaming_args.last_cache_position = eng.last_position          # qwen2/model_forward.py:117
     # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)
     if streaming_args.input_ids is not None:
         streaming_args.input_ids = torch.nn.functional.pad(streaming_args.input_ids, (0, out.n_new), "constant", 0)

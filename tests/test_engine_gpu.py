@@ -107,6 +107,16 @@ def test_tiny_qwen2_5_stream_structural_and_all_text():
     _compare(cfg, sd, 4, model, all_text=True)
 
 
+def test_tiny_streams_append_mode():
+    """pos_mode="append" on both families: un-rotated keys + per-row position history vs the oracle's rotated-K cache."""
+    for fam in ("qwen2", "qwen2_5"):
+        cfg, sd, model = _tiny_model(family=fam)
+        _compare(cfg, sd, 7, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+                 previous_text="a b c d e f g h i j k l m n o p", pos_mode="append")
+    cfg, sd, model = _tiny_model()
+    _compare(cfg, sd, 6, model, pos_mode="append")
+
+
 def test_tiny_stream_structural():
     cfg, sd, model = _tiny_model()
     _compare(cfg, sd, 8, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,

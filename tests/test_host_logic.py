@@ -99,8 +99,8 @@ def test_error_behaviour(tiny):
         S.streaming_inference(model=m, processor=S.SyntheticProcessor(), window_size=5, chunk_duration=2, video_path="synthetic://56x56@1fps")
     with pytest.raises(FileNotFoundError):
         S.streaming_inference(model=m, processor=S.SyntheticProcessor(), video_path="/no/such/video.mp4", model_base="Qwen2", quiet=True)
-    with pytest.raises(NotImplementedError):
-        S.streaming_inference(model=m, processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps", pos_mode="append",
+    with pytest.raises(AssertionError):   # StreamingArgs: pos_mode must be in ['append', 'shrink'] (streaming_args.py:4)
+        S.streaming_inference(model=m, processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps", pos_mode="grow",
                               model_base="Qwen2", duration=1, quiet=True)
     with pytest.raises(ValueError):       # pixel/token mismatch is the reference's ValueError (model_forward.py:56-61)
         m._svlm_engine.generate([151652, 151656, 151653, 5], None, [[1, 4, 4]], torch.zeros(16, 1176), [[1, 4, 4]], max_new_tokens=2)
@@ -170,6 +170,38 @@ def test_cache_object_contract_of_the_reference():
         pool.layer_kv(0)
     with pytest.raises(ValueError):
         pool.value_cache[0] = mk(24)
+
+
+def test_append_mode_positions_travel_with_their_rows(tiny):
+    """pos_mode="append": the product keeps un-rotated keys + each row's ORIGINAL position (KVPool.pos_rows, edited with the
+    slot table); the oracle follows the reference literally (keys rotated BEFORE caching, language_forward.py:89-97).  Same bits."""
+    for cfg in (tiny[0], C.tiny_2_5()):
+        sd = random_state_dict(cfg, 0, "cpu")
+        kw = dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
+                  previous_text="a b c d e f g h i j", pos_mode="append")
+        ref = H.run_oracle_stream(cfg, sd, 7, keep_logits=True, **kw)
+        res, trace, counts, log = H.run_engine_stream(_model(cfg, sd), 7, keep_logits=True, **kw)
+        assert [[list(t) for t in c] for c in trace] == [[list(t) for t in c] for c in ref["trace"]]
+        assert [e["new"] for e in log] == ref["new_tokens"]
+        for e, want in zip(log, ref["logits"]):
+            for a, b in zip(e["logits"], want):
+                assert torch.equal(a, b)
+        shr = H.run_oracle_stream(cfg, sd, 7, keep_logits=True, **{**kw, "pos_mode": "shrink"})
+        assert any(not torch.equal(a, b) for x, y in zip(ref["logits"][3:], shr["logits"][3:]) for a, b in zip(x, y)), \
+            "after the first eviction append and shrink must see different positions"
+
+
+def test_pool_position_history_follows_prune_and_move():
+    pool = _pool()
+    pool.slot_of_dev = torch.from_numpy(pool.slot_of)
+    _fill(pool, 60, 0)
+    pool.pos_rows[:, :60] = np.arange(60)[None, :] + np.array([[0.0], [100.0], [200.0]])
+    ref = list(range(60))
+    pool.prune(4, 13); del ref[4:14]
+    pool.move(30, 35, 7); ref = ref[:8] + ref[30:36] + ref[8:30] + ref[36:]
+    assert pool.pos_rows[0, :pool.length].tolist() == ref
+    assert pool.pos_rows[2, :pool.length].tolist() == [r + 200 for r in ref]
+    assert _rows(pool)[0] == ref                        # the K rows moved the same way
 
 
 def test_pool_prune_move_truncate_match_list_semantics():
