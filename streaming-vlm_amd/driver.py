@@ -417,3 +417,51 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
     if time_test:
         return time_results
     return responses
+
+
+# ----------------------------------------------------------------------------- CLI (reference: inference.py:524-561)
+def _cli(argv=None):
+    """`python -m streaming_vlm_amd.driver`: the reference's command line with its flag names and defaults.
+    `--model_path random:<2b|7b|2.5-3b|2.5-7b|tiny|tiny-2.5>[:seed]` and `--video_path synthetic://WxH@Ffps` run without
+    any checkpoint or video file; build-defined switches come after the reference's."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="streaming_vlm_amd.driver")
+    ap.add_argument("--pos_mode", type=str, default="shrink", choices=["append", "shrink"])
+    ap.add_argument("--all_text", action="store_true", default=False)
+    ap.add_argument("--model_path", type=str, default="mit-han-lab/StreamingVLM")
+    ap.add_argument("--model_base", type=str, choices=["Qwen2_5", "Qwen2"], default="Qwen2_5")
+    ap.add_argument("--video_path", type=str, default="synthetic://448x448@1fps")
+    ap.add_argument("--window_size", type=int, default=DEFAULT_WINDOW_SIZE)
+    ap.add_argument("--chunk_duration", type=int, default=DEFAULT_CHUNK_DURATION)
+    ap.add_argument("--text_round", type=int, default=DEFAULT_TEXT_ROUND)
+    ap.add_argument("--previous_text", type=str, default="")
+    ap.add_argument("--skip_first_chunk", type=int, default=0)
+    ap.add_argument("--recompute", action="store_true")
+    ap.add_argument("--temperature", type=float, default=DEFAULT_TEMPERATURE)
+    ap.add_argument("--text_sink", type=int, default=DEFAULT_TEXT_SINK)
+    ap.add_argument("--text_sliding_window", type=int, default=DEFAULT_TEXT_SLIDING_WINDOW)
+    ap.add_argument("--output_dir", type=str)
+    ap.add_argument("--emit_json", action="store_true", help="one JSON line per chunk on stdout")
+    ap.add_argument("--test_data_json", type=str, default=None)
+    ap.add_argument("--test_data_idx", type=int, default=None)
+    ap.add_argument("--gt_json", type=str, default=None)
+    ap.add_argument("--gt_idx", type=int, default=0)
+    # build-defined
+    ap.add_argument("--duration", type=int, default=TOTAL_VIDEO_DURATION, help="seconds of video to process")
+    ap.add_argument("--kv_policy", default="structural", choices=["structural", "sink_window", "none"])
+    ap.add_argument("--sink", type=int, default=4)
+    ap.add_argument("--window", type=int, default=2048)
+    ap.add_argument("--greedy", action="store_true", help="do_sample=False")
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args(argv)
+    kw = dict(vars(a))
+    kw["do_sample"] = not kw.pop("greedy")
+    if kw["output_dir"] is None:
+        os.makedirs("output", exist_ok=True)
+        kw["output_dir"] = (f"output/{a.model_path.replace('/', '_').replace(':', '_')}_viswin{a.window_size}_txtwin{a.text_round}"
+                            f"_prvsink{a.text_sink}_prvwin{a.text_sliding_window}_tprt{a.temperature}.vtt")
+    return streaming_inference(**kw)
+
+
+if __name__ == "__main__":
+    _cli()

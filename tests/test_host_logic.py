@@ -268,3 +268,18 @@ def test_patchify_matches_hf_layout():
     assert torch.allclose(pix[6], want)
     one, g1 = S.patchify(frames[:1])                                        # a single frame is duplicated to fill the temporal patch
     assert g1 == [[1, 2, 4]] and torch.allclose(one[:, :], S.patchify(torch.cat([frames[:1], frames[:1]]))[0])
+
+
+def test_cli_mirrors_the_reference_flags(tiny, tmp_path, monkeypatch, capsys):
+    """`python -m streaming_vlm_amd.driver` takes the reference's flags (inference.py:524-561), writes WebVTT and JSON lines."""
+    from streaming_vlm_amd import driver as drv
+    cfg, sd = tiny
+    monkeypatch.setattr(drv, "load_model_and_processor", lambda path, base: (_model(cfg, sd, ), S.SyntheticProcessor()))
+    vtt = tmp_path / "out.vtt"
+    out = drv._cli(["--model_path", "random:tiny", "--model_base", "Qwen2", "--video_path", "synthetic://56x56@1fps", "--duration", "2",
+                    "--window_size", "4", "--text_round", "4", "--output_dir", str(vtt), "--emit_json", "--quiet", "--greedy"])
+    assert len(out) == 2 and out[1]["start_time"] == 1 and out[1]["end_time"] == 2
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert [l["start"] for l in lines] == [0.0, 1.0] and all(l["type"] == "segment" for l in lines)
+    text = vtt.read_text()
+    assert text.startswith("WEBVTT\n\n00:00:00.000 --> 00:00:01.000\n") and "00:00:01.000 --> 00:00:02.000" in text
