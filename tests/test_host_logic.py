@@ -274,7 +274,8 @@ def test_cli_mirrors_the_reference_flags(tiny, tmp_path, monkeypatch, capsys):
     """`python -m streaming_vlm_amd.driver` takes the reference's flags (inference.py:524-561), writes WebVTT and JSON lines."""
     from streaming_vlm_amd import driver as drv
     cfg, sd = tiny
-    monkeypatch.setattr(drv, "load_model_and_processor", lambda path, base: (_model(cfg, sd, ), S.SyntheticProcessor()))
+    big = S.StreamingQwen2VL(cfg, sd, "cpu", ops=RefOps(), max_len=1024, max_new_tokens=20, use_graph=False)
+    monkeypatch.setattr(drv, "load_model_and_processor", lambda path, base: (big, S.SyntheticProcessor()))
     vtt = tmp_path / "out.vtt"
     out = drv._cli(["--model_path", "random:tiny", "--model_base", "Qwen2", "--video_path", "synthetic://56x56@1fps", "--duration", "2",
                     "--window_size", "4", "--text_round", "4", "--output_dir", str(vtt), "--emit_json", "--quiet", "--greedy"])
