@@ -76,3 +76,27 @@ def test_single_process_aggregate_and_shard():
     assert MS.shard(list(range(7)), 1, 3) == [1, 4]
     a = MS.aggregate(10, 200, 2.0, None)
     assert a == {"frames_per_sec": 5.0, "tokens_per_sec": 100.0, "t_max": 2.0, "per_rank_frames_per_sec": [5.0], "world": 1}
+
+
+def test_sample_sharded_worker_is_resumable_and_joins_jsonl(tmp_path):
+    """The LiveSports-3K-CC worker pattern (distributed_generate_streaming.py:44-150) on synthetic records: strided shards,
+    one JSON per record, finished records are skipped on a re-run, jsons -> jsonl."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C, multi_stream as MS
+    from streaming_vlm_amd.weights import random_state_dict
+    from ref_ops import RefOps
+    cfg = C.tiny()
+    model = S.StreamingQwen2VL(cfg, random_state_dict(cfg, 0, "cpu"), "cpu", ops=RefOps(), max_len=512, max_new_tokens=20, use_graph=False)
+    recs = [dict(video=f"synthetic://56x56@1fps?stream={i}", video_id=f"v{i}", event_id=i, begin=i, end=i + 2,
+                 event_title="t" if i % 2 else "", preasr_text="before" if i == 2 else "") for i in range(5)]
+    save = str(tmp_path / "tiny")
+    kw = dict(model_base="Qwen2", do_sample=False, max_new_tokens=4, suppress_eos=True, window_size=4, text_round=4)
+    d0 = MS.streaming_worker(0, 2, recs, model, S.SyntheticProcessor(), save, **kw)
+    d1 = MS.streaming_worker(1, 2, recs, model, S.SyntheticProcessor(), save, simple_ctx=True, **kw)
+    assert d0 == [0, 2, 4] and d1 == [1, 3]
+    assert MS.streaming_worker(0, 2, recs, model, S.SyntheticProcessor(), save, **kw) == []          # resumable: nothing left
+    out = MS.join_jsonl(save)
+    rows = [json.loads(l) for l in open(out)]
+    assert [r["event_id"] for r in rows] == [0, 1, 2, 3, 4] and all(isinstance(r["pred"], str) and r["pred"] for r in rows)
+    assert rows[3]["begin"] == 3 and rows[3]["end"] == 5
