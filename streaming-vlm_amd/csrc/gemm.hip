@@ -408,6 +408,35 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
       if (cost < best_cost) { best_cost = cost; best_bm = bm_c; best_splits = sp; }
     }
   }
+  // ---- tuned plans: shapes of the supported models measured on MI355X (tools/gemm_tune_table.py, cold weights).  The cost
+  // model above mis-ranks some of them (it knows nothing of co-resident workgroups sharing a CU's LDS-DMA stream); an entry
+  // applies to its exact (N, K) and row bucket ceil(M/64) +- 1.
+  struct GemmPlan { int mb, N, K, bm, splits; };
+  static const GemmPlan kTunedPlans[] = {
+      {5, 1536, 8960, 64, 4},      // Qwen2-VL-2B down_proj, prefill: 24.6 us vs 28.3 us for the cost model's choice
+      {5, 4608, 3584, 64, 2},      // 7B qkv: 26.5 vs 29.9
+      {5, 3584, 3584, 64, 3},      // 7B o_proj: 22.9 vs 27.8
+      {5, 3584, 18944, 128, 3},    // 7B down_proj: 76.0 vs 123.6
+      {5, 2560, 2048, 64, 3},      // Qwen2.5-VL-3B qkv: 16.3 vs 18.1
+      {5, 2048, 2048, 64, 3},      // 3B o_proj: 14.4 vs 15.6
+      {5, 2048, 11008, 64, 4},     // 3B down_proj: 33.3 vs 43.2
+      {16, 1280, 5120, 128, 3},    // ViT fc2 (1024 patches): 31.3 vs 35.0
+      {16, 1280, 3424, 128, 3},    // Qwen2.5 ViT down_proj: 28.7 vs 31.2
+      {4, 5120, 5120, 128, 3},     // merger mlp.0 (256 merged tokens): 30.1 vs 37.8
+      {4, 1536, 5120, 64, 5},      // merger mlp.2 -> 2B: 17.0 vs 21.3
+      {4, 3584, 5120, 128, 4},     // merger mlp.2 -> 7B: 25.1 vs 36.1
+      {4, 2048, 5120, 64, 4},      // merger mlp.2 -> 3B: 19.7 vs 21.5
+  };
+  if (getenv("SVLM_GEMM_NO_TABLE") == nullptr) {
+    const int mb = (M + 63) / 64;
+    for (const GemmPlan& p : kTunedPlans) {
+      if (p.N == N && p.K == K && mb >= p.mb - 1 && mb <= p.mb + 1 && (p.splits == 1 || (ws != nullptr && (long long)p.splits * M * N * 4 <= ws_bytes))) {
+        best_bm = p.bm;
+        best_splits = p.splits;
+        break;
+      }
+    }
+  }
   if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
     best_bm = atoi(force) == 128 && M > 64 ? 128 : 64;
     if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;

@@ -63,6 +63,11 @@ def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
     (1024, 1280, 1280, True, True, 0),      # ViT proj (split-K 2)
     (64, 256, 4096, True, False, 1),        # deep split-K with activation
     (200, 128, 1000, False, False, 0),      # K not a multiple of 64, split-K tail
+    # shapes that take their (tile rows, split-K) from the tuned-plan table rather than from the cost model
+    (290, 3584, 18944, False, True, 0),     # 7B down_proj (BM 128, 3 splits)
+    (290, 4608, 3584, True, False, 0),      # 7B qkv (BM 64, 2 splits)
+    (1024, 1280, 3424, True, True, 0),      # Qwen2.5 ViT down_proj (padded intermediate size)
+    (256, 3584, 5120, True, False, 0),      # merger mlp.2 -> 7B
 ])
 def test_gemm(ops, ref, M, N, K, bias, res, act):
     A, W = rnd((M, K), 1), rnd((N, K), 2, 0.05)
@@ -71,6 +76,19 @@ def test_gemm(ops, ref, M, N, K, bias, res, act):
     want = ref.gemm(A, W, b, r, act=act)
     got = ops.gemm(A.cuda(), W.cuda(), b.cuda() if bias else None, r.cuda() if res else None, act=act)
     close(f"gemm {M}x{N}x{K} act{act}", got, want)
+
+
+@pytest.mark.parametrize("bm,splits", [(64, 1), (64, 5), (128, 1), (128, 3), (128, 8)])
+def test_gemm_every_plan_is_numerically_the_same_op(ops, ref, bm, splits, monkeypatch):
+    """Tile height and split-K are performance choices only: forced through the tuning switches, each plan must pass the
+    same bar as the default one."""
+    monkeypatch.setenv("SVLM_GEMM_BM", str(bm))
+    monkeypatch.setenv("SVLM_GEMM_SPLITS", str(splits))
+    M, N, K = 290, 1536, 8960
+    A, W, b, r_ = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.1), rnd((M, N), 4)
+    want = ref.gemm(A, W, bias=b, residual=r_)
+    got = ops.gemm(A.cuda(), W.cuda(), bias=b.cuda(), residual=r_.cuda())
+    close(f"gemm plan bm{bm} s{splits}", got, want)
 
 
 def test_gemm_inplace_residual(ops, ref):
