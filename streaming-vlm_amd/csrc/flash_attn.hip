@@ -24,6 +24,7 @@
 // Pipeline: two LDS stages + a two-slot register ring; the global loads of key tile t+3 are issued while tile t is
 // computed (two iterations to land), one barrier per 32-key tile.
 #include "common.h"
+#include <stdlib.h>
 
 #define FA_KT 32        // keys per tile
 #define FA_VLD 144      // V LDS row stride (bf16): 288 B = 8 banks (mod 64) per key -> conflict-free ds_read_b64_tr_b16
@@ -297,11 +298,14 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restr
   *reinterpret_cast<u32x2_t*>(out + (size_t)t * o_row_stride + h * D + c * 4) = r;
 }
 
-// Key splits of a prefill: enough workgroups to cover the chip (a 290-row chunk of a 12-head model is 60 query tiles),
-// at least four 32-key tiles per split, at most 8.
+// Key splits of a prefill: ~450 workgroups in all (measured, tools/prefill_attn_splits.py: a 290-row chunk is 60 query tiles on the
+// 12-head 2B model -> 8 splits, 83 -> 35 us; 140 tiles on the 28-head 7B model -> 3 splits, 151 -> 86 us), at least four 32-key
+// tiles per split, at most 8.
 static inline int prefill_splits(int T, int L, int Hq) {
   const int base = ((T + 63) / 64) * Hq;
-  int ns = base > 0 ? 256 / base : 1;
+  static const int force = getenv("SVLM_PREFILL_SPLITS") ? atoi(getenv("SVLM_PREFILL_SPLITS")) : 0;      // tuning aid
+  if (force > 0) return force > 8 ? 8 : force;
+  int ns = base > 0 ? (448 + base / 2) / base : 1;
   const int by_len = L / (4 * FA_KT);
   ns = ns < by_len ? ns : by_len;
   return ns < 1 ? 1 : (ns > 8 ? 8 : ns);
