@@ -167,7 +167,7 @@ extern "C" int svlm_gemv_bf16(const void* x, const void* W, int ldw, const void*
   if (N >= 16384) {
     gemv_bf16_kernel<4><<<(N + 15) / 16, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                                                      (const bf16_t*)residual, (bf16_t*)y, y_f32, N, K, act);
-  } else if (N >= 4096) {
+  } else if (N >= 4096 || (long long)N * K >= (8LL << 20)) {      // enough rows, or rows long enough to want 2 per wave
     gemv_bf16_kernel<2><<<(N + 7) / 8, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                                                    (const bf16_t*)residual, (bf16_t*)y, y_f32, N, K, act);
   } else {
