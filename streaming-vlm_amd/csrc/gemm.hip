@@ -416,7 +416,7 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
       {5, 1536, 8960, 64, 4},      // Qwen2-VL-2B down_proj, prefill: 24.6 us vs 28.3 us for the cost model's choice
       {5, 4608, 3584, 64, 2},      // 7B qkv: 26.5 vs 29.9
       {5, 3584, 3584, 64, 3},      // 7B o_proj: 22.9 vs 27.8
-      {5, 3584, 18944, 128, 3},    // 7B down_proj: 76.0 vs 123.6
+      {5, 3584, 18944, 320, 8},    // 7B down_proj: 66.2 (all rows in one 320-row tile) vs 123.6
       {5, 2560, 2048, 64, 3},      // Qwen2.5-VL-3B qkv: 16.3 vs 18.1
       {5, 2048, 2048, 64, 3},      // 3B o_proj: 14.4 vs 15.6
       {5, 2048, 11008, 64, 4},     // 3B down_proj: 33.3 vs 43.2
@@ -438,7 +438,8 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
     }
   }
   if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
-    best_bm = atoi(force) == 128 && M > 64 ? 128 : 64;
+    const int fb = atoi(force);
+    best_bm = (fb == 192 || fb == 320) ? fb : (fb == 128 && M > 64 ? 128 : 64);
     if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
     if ((long long)best_splits * M * N * 4 > ws_bytes || ws == nullptr || K < 1024) best_splits = 1;
   }
@@ -467,6 +468,10 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
     attr_done = true;
   }
   const bool dma = (K % GEMM_BK == 0) && getenv("SVLM_GEMM_NO_DMA") == nullptr;
+  if (!dma && (bm == 192 || bm == 320)) {
+    svlm_set_error("svlm_gemm_bf16: tall tiles need K %% 64 == 0");
+    return SVLM_EINVAL;
+  }
   if (dma) {
     // ring depth: 3 stages (72 KB at BM = 64: two workgroups per CU; 96 KB at BM = 128); 4 measured slower, see the kernel
     constexpr int NS2 = 3, NS4 = 3;
@@ -481,7 +486,27 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
       }
       dma_attr_done = true;
     }
-    if (small) {
+    if (bm == 192 || bm == 320) {
+      // tall tiles for skinny-M weight-streaming GEMMs (prefill: M ~ 290): 2 x 192 rows, or ALL rows in one 320-row tile so that
+      // W is streamed exactly once; 320 rows leave LDS for a 2-stage ring only
+      constexpr int DLDS6 = 3 * (192 + GEMM_BN) * 128, DLDS10 = 2 * (320 + GEMM_BN) * 128;
+      static bool tall_attr_done = false;
+      if (!tall_attr_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<6, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS6);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<10, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS10);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+          svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", DLDS10, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+          return SVLM_ELAUNCH;
+        }
+        tall_attr_done = true;
+      }
+      if (bm == 192)
+        gemm_glds_kernel<6, 3><<<grid, 256, DLDS6, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                                 (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+      else
+        gemm_glds_kernel<10, 2><<<grid, 256, DLDS10, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                                  (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+    } else if (small) {
       gemm_glds_kernel<2, NS2><<<grid, 256, DLDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
     } else {

@@ -11,6 +11,7 @@ o = HipOps()
 bf = torch.bfloat16
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.05).to(bf)
 MP, MV = 290, 1024          # prefill rows of a 448x448 chunk (bucket ceil(M/64) = 5), ViT patches of a 448x448 grid (bucket 16)
+only = os.environ.get("GROUPS")
 shapes = {
     "2b": [(MP, 2048, 1536), (MP, 1536, 1536), (MP, 17920, 1536), (MP, 1536, 8960)],
     "7b": [(MP, 4608, 3584), (MP, 3584, 3584), (MP, 37888, 3584), (MP, 3584, 18944)],
@@ -40,6 +41,8 @@ def timeit(fn, n_w):
 
 plans = []
 for group, lst in shapes.items():
+    if only and group not in only.split(","):
+        continue
     for M, N, K in lst:
         n_w = max(4, min(28, int(1.2e9 // (N * K * 2))))          # > 1 GB of distinct weights: colder than the Infinity Cache
         Ws = [r(N, K) for _ in range(n_w)]
@@ -50,9 +53,11 @@ for group, lst in shapes.items():
         os.environ["SVLM_GEMM_NO_TABLE"] = "1"
         base = timeit(fn, n_w)
         cands = []
-        for bm in (64, 128):
+        for bm in (64, 128, 192, 320):
             for sp in (1, 2, 3, 4, 5, 6, 8):
                 if sp > 1 and K < 1024:
+                    continue
+                if bm > 128 and (K % 64 or M <= 128):
                     continue
                 os.environ["SVLM_GEMM_BM"], os.environ["SVLM_GEMM_SPLITS"] = str(bm), str(sp)
                 cands.append((timeit(fn, n_w), bm, sp))
@@ -60,7 +65,8 @@ for group, lst in shapes.items():
         cands.sort()
         t, bm, sp = cands[0]
         keep = t < 0.96 * base
-        print(f"{group:8s} M={M:5d} N={N:6d} K={K:6d}: model {base:7.2f} us, best {t:7.2f} us (bm{bm}, s{sp}){'  <- table' if keep else ''}", flush=True)
+        print(f"{group:8s} M={M:5d} N={N:6d} K={K:6d}: model {base:7.2f} us, best {t:7.2f} us (bm{bm}, s{sp}){'  <- table' if keep else ''}   top: "
+              + " ".join(f"{t_:.1f}(bm{b_},s{s_})" for t_, b_, s_ in cands[:5]), flush=True)
         if keep:
             plans.append({"group": group, "mb": (M + 63) // 64, "N": N, "K": K, "bm": bm, "splits": sp, "us": round(t, 2), "model_us": round(base, 2)})
         del Ws
