@@ -225,3 +225,16 @@ def test_full_size_2b_two_chunks_448():
     sd = random_state_dict(cfg, 0, "cpu")
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
     _compare(cfg, sd, 2, model, size=448, window=256, max_new=4)
+
+
+def test_full_size_qwen2_5_vl_3b_two_chunks_448():
+    """Qwen2.5-VL-3B at FULL size (36 LLM layers, 32 windowed ViT blocks, intermediate 3420 padded to 3424), 448x448 frames, two
+    chunks with an eviction in between: same bars as the Qwen2-VL-2B full-size test."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    from streaming_vlm_amd.weights import random_state_dict
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = C.qwen2_5_vl_3b()
+    sd = random_state_dict(cfg, 0, "cpu")
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
+    _compare(cfg, sd, 2, model, size=448, window=256, max_new=4)
