@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Cost of hiding the look-ahead ViT under the decode steps: 19 decode-graph replays alone, with a ViT pass on the side stream,
+and the ViT pass alone."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import streaming_vlm_amd as S
+from streaming_vlm_amd import config as C
+from streaming_vlm_amd.weights import random_state_dict
+from streaming_vlm_amd.synthetic import ResidentVideo, ResidentProcessor
+
+cfg = C.qwen2_vl_2b()
+model = S.StreamingQwen2VL(cfg, random_state_dict(cfg, 0, "cuda"), "cuda", max_len=2700, max_new_tokens=20)
+eng = model._svlm_engine
+video = ResidentVideo(12, 448, 1.0, 0, "cuda")
+S.streaming_inference(model=model, processor=ResidentProcessor(), video=video, model_base="Qwen2", duration=10, previous_text="",
+                      kv_policy="sink_window", sink=4, window=2048, do_sample=False, max_new_tokens=20, suppress_eos=True, quiet=True)
+torch.cuda.synchronize()
+g = eng._graph
+pix, grid = video.chunks[3].pixel_values, video.chunks[3].grid
+side = torch.cuda.Stream()
+def t(fn, n=5):
+    best = 1e9
+    for _ in range(n):
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e))
+    return best
+def decode():
+    eng.state.copy_(torch.tensor([2100, 0], dtype=torch.int32))
+    for _ in range(19): g.replay()
+def vit():
+    eng.vision_forward(pix, grid)
+def both():
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.vision_forward(pix, grid)
+    decode()
+    torch.cuda.current_stream().wait_stream(side)
+print(f"decode x19 alone {t(decode):.3f} ms | vit alone {t(vit):.3f} ms | decode with vit on a side stream {t(both):.3f} ms")
