@@ -39,3 +39,43 @@ def both():
     decode()
     torch.cuda.current_stream().wait_stream(side)
 print(f"decode x19 alone {t(decode):.3f} ms | vit alone {t(vit):.3f} ms | decode with vit on a side stream {t(both):.3f} ms")
+
+# ---- the same question for the prefill: ViT of the next chunk beside THIS chunk's prefill (both GEMM streams, one tile per CU each)
+import copy
+from streaming_vlm_amd.engine import _VitRun
+class _Proxy:
+    def __init__(self, eng, ops):
+        self.__dict__["_e"], self.__dict__["ops"] = eng, ops
+    def __getattr__(self, k):
+        return getattr(self._e, k)
+o2 = copy.copy(eng.ops); o2._gemm_ws = {}              # separate split-K scratch for the side stream
+proxy = _Proxy(eng, o2)
+T, L_before = 290, 1840
+cache = eng.new_cache(); cache.reserve(L_before + T + 20); cache.commit(L_before); cache.sync_device()
+idx = torch.randint(0, 1000, (T,), dtype=torch.int32, device="cuda")
+def prefill():
+    eng._prefill(cache, idx, None, T, L_before)
+def vit2():
+    run = _VitRun(proxy, pix, grid); run.blocks(0, cfg.vision.depth); run.finish()
+def both2():
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        vit2()
+    prefill()
+    torch.cuda.current_stream().wait_stream(side)
+prefill(); vit2(); torch.cuda.synchronize()
+print(f"prefill alone {t(prefill):.3f} ms | vit alone {t(vit2):.3f} ms | prefill with vit on a side stream {t(both2):.3f} ms")
+def all3():
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        vit2()
+    prefill(); decode()
+    torch.cuda.current_stream().wait_stream(side)
+def serial_then_overlap():
+    prefill()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        vit2()
+    decode()
+    torch.cuda.current_stream().wait_stream(side)
+print(f"prefill+decode with vit started at the prefill {t(all3):.3f} ms | vit started after the prefill (today) {t(serial_then_overlap):.3f} ms")
