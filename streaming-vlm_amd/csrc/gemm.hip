@@ -206,7 +206,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
   constexpr int BM = 32 * TM;
   constexpr int A_INST = BM / 32;               // 1-KiB DMA pieces (8 rows x 128 B) per wave per tile: A
   constexpr int W_INST = GEMM_BN / 32;          // ... and W
+#if GEMM_DIAG == 3                               // DMA-only loop that streams W alone: is the DMA stream bound per byte or per step?
+  constexpr int NPT = W_INST;
+#else
   constexpr int NPT = A_INST + W_INST;          // DMA instructions per wave per tile
+#endif
   constexpr int STAGE_B = (BM + GEMM_BN) * 128; // bytes per stage
   unsigned char* smem = gemm_dyn_smem;
 
@@ -250,8 +254,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
   auto issue = [&](int kt, int stage) {
     unsigned char* sa = smem + stage * STAGE_B;
     unsigned char* sw = sa + BM * 128;
+#if GEMM_DIAG != 3
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) GLDS(a_src[i] + kt * GEMM_BK, sa + (wave * A_INST + i) * 1024);
+#endif
 #pragma unroll
     for (int i = 0; i < W_INST; ++i) GLDS(w_src[i] + kt * GEMM_BK, sw + (wave * W_INST + i) * 1024);
   };
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
     else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NS);
-#if GEMM_DIAG != 2
+#if GEMM_DIAG != 2 && GEMM_DIAG != 3
     compute(kt % NS);
 #endif
   }
