@@ -385,27 +385,29 @@ __global__ __launch_bounds__(256) void decode_attn_long_kernel(
 template <int NW, int DS>
 __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
                                                                       const float* __restrict__ ws_acc, const int* __restrict__ len_dev,
-                                                                      int len_add, bf16_t* __restrict__ out, int Hq, int chunk) {
+                                                                      int len_add, bf16_t* __restrict__ out, int Hq, int chunk, int ns_max) {
   constexpr int CW = 64 / DS;            // lanes across the workgroup's columns (2 columns each)
   constexpr int SUB = DS;                // split sub-slots per wave
   constexpr int STRIDE = NW * SUB;       // splits covered per step of u
-  const int L = (len_dev ? *len_dev : 0) + len_add;
-  const int ns = (L + chunk - 1) / chunk;
   const int hq = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = lane % CW, sub = lane / CW;
   const int col = blockIdx.y * (DA_D / DS) + 2 * cl;
   const int first = wave * SUB + sub;
+  // The first batch does not wait for the length: slots beyond the live splits are valid memory of the workspace (clamped to
+  // its last slot) whose stale contents are skipped below, so the partial loads and the length load are ONE round trip, not two.
   float m_[DA_CB], l_[DA_CB];
   float2 v_[DA_CB];
 #pragma unroll
   for (int u = 0; u < DA_CB; ++u) {
-    const int i0 = min(first + STRIDE * u, ns - 1);
+    const int i0 = min(first + STRIDE * u, ns_max - 1);
     const size_t p = (size_t)i0 * Hq + hq;
     m_[u] = ws_m[p];
     l_[u] = ws_l[p];
     v_[u] = *reinterpret_cast<const float2*>(ws_acc + p * DA_D + col);
   }
+  const int L = (len_dev ? *len_dev : 0) + len_add;
+  const int ns = (L + chunk - 1) / chunk;
   // global max over splits (every wave computes it redundantly: ns floats)
   float mx = -1e30f;
   for (int i = lane; i < ns; i += 64) mx = fmaxf(mx, ws_m[(size_t)i * Hq + hq]);
@@ -504,11 +506,11 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
   // measured on MI355X (tools/decode_attn_sweep.py): column halves pay from ~64 splits (7B @ window 4096: 13.8 -> 12.3 us),
   // column quarters on 16 waves from ~200 (32k keys: 26.3 -> 22.8 us); below that the extra workgroups only add latency
   if (force_ds == 4 || (force_ds == 0 && ns_max > 192)) {
-    decode_attn_combine_kernel<16, 4><<<dim3(Hq, 4), 1024, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+    decode_attn_combine_kernel<16, 4><<<dim3(Hq, 4), 1024, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk, ns_max);
   } else if (force_ds == 2 || (force_ds == 0 && ns_max > 64)) {
-    decode_attn_combine_kernel<4, 2><<<dim3(Hq, 2), 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+    decode_attn_combine_kernel<4, 2><<<dim3(Hq, 2), 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk, ns_max);
   } else {                     // bounded windows: up to two batches per wave on 4 waves
-    decode_attn_combine_kernel<4, 1><<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk);
+    decode_attn_combine_kernel<4, 1><<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk, ns_max);
   }
   return svlm_check_launch("svlm_decode_attn_ropeload(combine)");
 }
