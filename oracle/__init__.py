@@ -4,7 +4,7 @@ This package is a plain eager-PyTorch / numpy restatement of the algorithm of
 rahim-xelpmoc/streaming-vlm's per-chunk streaming loop (reference files are
 cited function by function as ``file:line`` relative to ``/root/reference``).
 
-Rules (enforced by tests/test_layout.py):
+Rules (enforced by tests/test_abi_layout.py):
   * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
     ``cpu_baseline`` leg may import anything from here;
   * the product package (``streaming-vlm_amd/``) never imports it and never
