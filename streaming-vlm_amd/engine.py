@@ -170,7 +170,7 @@ class _VitRun:
 
 class SvlmEngine:
     def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, max_len: int = 4096, max_new_tokens: int = 32,
-                 decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None):
+                 decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None, kv_slack: float = 1.0, kv_page_tokens: int = 16):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()                      # raises when the HIP extension / GPU is missing
@@ -183,6 +183,7 @@ class SvlmEngine:
             raise ValueError("LLM head_dim must be 128 with mrope sections summing to 64")
         self.max_len = int(max_len)
         self.max_new = int(max_new_tokens)
+        self.kv_slack, self.kv_page_tokens = float(kv_slack), int(kv_page_tokens)      # KV pool head-room over max_len, page size
         if decode_chunk is None:
             decode_chunk = self.pick_decode_chunk(self.max_len, tc.num_kv_heads)
         self.decode_chunk = int(os.environ.get("SVLM_DECODE_CHUNK", decode_chunk))
@@ -238,9 +239,10 @@ class SvlmEngine:
         return 256 if max_len * n_kv_heads >= 100_000 else 64
 
     # ------------------------------------------------------------------ cache
-    def new_cache(self, page_tokens: int = 16, slack: float = 1.0) -> KVPool:
+    def new_cache(self, page_tokens: Optional[int] = None, slack: Optional[float] = None) -> KVPool:
         tc = self.cfg.text
-        return KVPool(tc.num_layers, tc.num_kv_heads, tc.head_dim, self.max_len, self.device, self.ops, page_tokens, slack)
+        return KVPool(tc.num_layers, tc.num_kv_heads, tc.head_dim, self.max_len, self.device, self.ops,
+                      self.kv_page_tokens if page_tokens is None else page_tokens, self.kv_slack if slack is None else slack)
 
     # ------------------------------------------------------------------ ViT
     def _vit_rope(self, grid_thw):
