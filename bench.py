@@ -263,19 +263,44 @@ def roofline_pass(model, args, kv_len):
     xv = torch.randn((N, E), device=dev).to(torch.bfloat16)
     qv = torch.randn((N, 3 * E), device=dev).to(torch.bfloat16)
     av = torch.randn((N, E), device=dev).to(torch.bfloat16)
-    fv = torch.randn((N, F), device=dev).to(torch.bfloat16)
+    if vc.arch == "qwen2_5":           # RMSNorm / SwiGLU tower: gate|up fused (padded intermediate), windowed attention
+        Fp = vc.mlp_padded
+        guv = torch.randn((N, 2 * Fp), device=dev).to(torch.bfloat16)
+        hv = torch.randn((N, Fp), device=dev).to(torch.bfloat16)
 
-    def vit_gemms():
-        for b in w.vit:
-            o.gemm(xv, b["qkv_w"], bias=b["qkv_b"], out=qv)
-            o.gemm(av, b["proj_w"], bias=b["proj_b"], residual=xv, out=xv)
-            o.gemm(xv, b["fc1_w"], bias=b["fc1_b"], out=fv, act=1)
-            o.gemm(fv, b["fc2_w"], bias=b["fc2_b"], residual=xv, out=xv)
-    fl = gflops(N, 3 * E, E) + gflops(N, E, E) + 2 * gflops(N, F, E)
-    by = gbytes(N, 3 * E, E) + gbytes(N, E, E) + 2 * gbytes(N, F, E)
-    timed("gemm_bf16_kernel(vit: qkv,proj,fc1,fc2)", 4 * vc.depth, 4 * vc.depth, by / 4, fl / 4, vit_gemms)
-    timed(f"flash_attn_kernel<{dv},{96 if dv == 80 else dv}>(vit)", vc.depth, vc.depth, 2 * N * 4 * Hh * dv, 4.0 * N * N * Hh * dv,
-          lambda: [o.vit_attn(qv, 1, N, Hh, dv, 1.0 / math.sqrt(dv), out=av) for _ in range(vc.depth)])
+        def vit_gemms():
+            for b in w.vit:
+                o.gemm(xv, b["qkv_w"], bias=b["qkv_b"], out=qv)
+                o.gemm(av, b["proj_w"], bias=b["proj_b"], residual=xv, out=xv)
+                o.gemm(xv, b["gu_w"], bias=b["gu_b"], out=guv)
+                o.gemm(hv, b["down_w"], bias=b["down_b"], residual=xv, out=xv)
+        fl = gflops(N, 3 * E, E) + gflops(N, E, E) + 3 * gflops(N, Fp, E)
+        by = gbytes(N, 3 * E, E) + gbytes(N, E, E) + 3 * gbytes(N, Fp, E)
+        timed("gemm_bf16_kernel(vit2.5: qkv,proj,gate_up,down)", 4 * vc.depth, 4 * vc.depth, by / 4, fl / 4, vit_gemms)
+        plan = eng._vit_windows([[1, args.size // 14, args.size // 14]])
+        n_full = len(vc.fullatt_block_indexes)
+
+        def vit_attn():
+            for bi in range(vc.depth):
+                for row, n, ln in (plan["full_runs"] if bi in vc.fullatt_block_indexes else plan["win_runs"]):
+                    o.vit_attn(qv[row:row + n * ln], n, ln, Hh, dv, 1.0 / math.sqrt(dv), out=av[row:row + n * ln])
+        wl = plan["win_runs"][0][2]
+        timed(f"flash_attn_kernel<{dv},{96 if dv == 80 else dv}>(vit2.5: {vc.depth - n_full} windowed + {n_full} full blocks)", vc.depth, vc.depth,
+              2 * N * 4 * Hh * dv, 4.0 * N * Hh * dv * (n_full * N + (vc.depth - n_full) * wl) / vc.depth, vit_attn)
+    else:
+        fv = torch.randn((N, F), device=dev).to(torch.bfloat16)
+
+        def vit_gemms():
+            for b in w.vit:
+                o.gemm(xv, b["qkv_w"], bias=b["qkv_b"], out=qv)
+                o.gemm(av, b["proj_w"], bias=b["proj_b"], residual=xv, out=xv)
+                o.gemm(xv, b["fc1_w"], bias=b["fc1_b"], out=fv, act=1)
+                o.gemm(fv, b["fc2_w"], bias=b["fc2_b"], residual=xv, out=xv)
+        fl = gflops(N, 3 * E, E) + gflops(N, E, E) + 2 * gflops(N, F, E)
+        by = gbytes(N, 3 * E, E) + gbytes(N, E, E) + 2 * gbytes(N, F, E)
+        timed("gemm_bf16_kernel(vit: qkv,proj,fc1,fc2)", 4 * vc.depth, 4 * vc.depth, by / 4, fl / 4, vit_gemms)
+        timed(f"flash_attn_kernel<{dv},{96 if dv == 80 else dv}>(vit)", vc.depth, vc.depth, 2 * N * 4 * Hh * dv, 4.0 * N * N * Hh * dv,
+              lambda: [o.vit_attn(qv, 1, N, Hh, dv, 1.0 / math.sqrt(dv), out=av) for _ in range(vc.depth)])
 
     results.sort(key=lambda r: -r["ms_per_chunk"])
     # dominant = the single kernel SYMBOL with the most time per chunk (pairs timed together are listed, not ranked)
