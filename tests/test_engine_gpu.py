@@ -292,3 +292,16 @@ def test_sampling_recompute_and_teacher_forcing_run_on_the_device(tmp_path):
     cfg, sd, model = _tiny_model()
     res = S.streaming_inference(model=model, do_sample=False, suppress_eos=True, gt_json=str(gt), gt_idx=0, **kw)
     assert len(res) == 4
+
+
+def test_tiny_stream_with_the_7b_head_grouping():
+    """7 query heads per kv head (Qwen2-VL-7B / Qwen2.5-VL-7B: 28 / 4) end to end: the MFMA decode attention pads the group
+    to 16 columns, the fused QKV kernel appends 1 kv head."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    from streaming_vlm_amd.weights import random_state_dict
+    cfg = C.tiny()
+    cfg.text.num_heads, cfg.text.num_kv_heads = 7, 1
+    sd = random_state_dict(cfg, 0, "cpu")
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8)
+    _compare(cfg, sd, 5, model)
