@@ -382,8 +382,94 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   }
 }
 
+// Split-K reduce fused with the RMSNorm that follows a residual-stream GEMM (o_proj -> post_attention_layernorm, down_proj ->
+// the next layer's input_layernorm; qwen2/language_forward.py:183,195-200): one workgroup per row keeps the reduced bf16 row in
+// registers, so the row is normalised without a second launch and without re-reading it.  Same roundings as
+// gemm_splitk_reduce_kernel followed by rmsnorm_kernel.
+#define RN_IT 2       // 2048-column passes of the workgroup: N <= 4096
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const float* __restrict__ partial, int splits,
+                                                                      const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
+                                                                      bf16_t* C, int ldc, int M, int N, int act,
+                                                                      const bf16_t* __restrict__ norm_w, float eps, bf16_t* __restrict__ XN, int ldxn) {
+  // one workgroup per row, 8 columns per thread and pass: all slab loads of a thread are independent and issued together
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const size_t slab = (size_t)M * N;
+  float y[RN_IT][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < RN_IT; ++it) {
+    const int n = it * 2048 + tid * 8;
+    if (n < N) {
+      float acc[8];
+      const float* p0 = partial + (size_t)m * N + n;
+      f32x4_t a = *reinterpret_cast<const f32x4_t*>(p0), b = *reinterpret_cast<const f32x4_t*>(p0 + 4);
+      for (int z = 1; z < splits; ++z) {
+        const f32x4_t pa = *reinterpret_cast<const f32x4_t*>(p0 + z * slab), pb = *reinterpret_cast<const f32x4_t*>(p0 + z * slab + 4);
+        a += pa; b += pb;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc[i] = a[i]; acc[4 + i] = b[i]; }
+      if (bias) {
+        float bf[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(bias + n), bf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += bf[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = apply_act(rbf(acc[i]), act);
+      if (residual) {
+        float rf[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(residual + (size_t)m * ldr + n), rf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += rf[i];
+      }
+      const u32x4_t o = pack8(acc);
+      *reinterpret_cast<u32x4_t*>(C + (size_t)m * ldc + n) = o;
+      unpack8(o, y[it]);                                   // the bf16 values the norm kernel would read back
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += y[it][i] * y[it][i];
+    }
+  }
+  __shared__ float red[4];
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float r = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+#pragma unroll
+  for (int it = 0; it < RN_IT; ++it) {
+    const int n = it * 2048 + tid * 8;
+    if (n < N) {
+      float g[8], f[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(norm_w + n), g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = g[i] * rbf(y[it][i] * r);
+      *reinterpret_cast<u32x4_t*>(XN + (size_t)m * ldxn + n) = pack8(f);
+    }
+  }
+}
+
+extern "C" int svlm_rmsnorm(const void* x, const void* w, void* y, int rows, int cols, float eps, void* stream);
+
+static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                     void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream,
+                     const void* norm_w, float eps, void* XN, int ldxn);
+
 extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                               void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream) {
+  return gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, stream, nullptr, 0.f, nullptr, 0);
+}
+
+extern "C" int svlm_gemm_bf16_norm(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                                   void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
+                                   const void* norm_w, float eps, void* XN, int ldxn, void* stream) {
+  SVLM_CHECK_ARG(norm_w != nullptr && XN != nullptr && N % 8 == 0 && ldc % 8 == 0 && ldxn % 8 == 0 && ldxn >= N && eps > 0.f,
+                 "svlm_gemm_bf16_norm: needs a norm weight, an output with 16-B aligned rows and N %% 8 == 0 (N=%d ldc=%d ldxn=%d)", N, ldc, ldxn);
+  return gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, stream, norm_w, eps, XN, ldxn);
+}
+
+static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                     void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream,
+                     const void* norm_w, float eps, void* XN, int ldxn) {
   SVLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "svlm_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
   SVLM_CHECK_ARG(K % 8 == 0 && N % 4 == 0, "svlm_gemm_bf16: K=%d must be a multiple of 8 and N=%d of 4", K, N);
   SVLM_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0),
@@ -527,10 +613,21 @@ extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, co
                                              (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
   }
   int rc = svlm_check_launch("svlm_gemm_bf16");
-  if (rc || splits == 1) return rc;
-  const size_t total = (size_t)M * (N / 4);
-  int rg = (int)((total + 255) / 256);
-  rg = rg > 2048 ? 2048 : rg;
-  gemm_splitk_reduce_kernel<<<rg, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N, act);
-  return svlm_check_launch("svlm_gemm_bf16(split-K reduce)");
+  if (rc) return rc;
+  if (splits > 1 && norm_w != nullptr && N <= 2048 * RN_IT) {      // reduce + RMSNorm of the reduced row in one launch
+    gemm_splitk_reduce_norm_kernel<<<M, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C,
+                                                                ldc, M, N, act, (const bf16_t*)norm_w, eps, (bf16_t*)XN, ldxn);
+    return svlm_check_launch("svlm_gemm_bf16_norm(split-K reduce + norm)");
+  }
+  if (splits > 1) {
+    const size_t total = (size_t)M * (N / 4);
+    int rg = (int)((total + 255) / 256);
+    rg = rg > 2048 ? 2048 : rg;
+    gemm_splitk_reduce_kernel<<<rg, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C, ldc, M, N, act);
+    rc = svlm_check_launch("svlm_gemm_bf16(split-K reduce)");
+    if (rc) return rc;
+  }
+  if (norm_w == nullptr) return SVLM_OK;
+  SVLM_CHECK_ARG(ldc == N && ldxn == N, "svlm_gemm_bf16_norm: the unfused norm needs contiguous rows (ldc=%d ldxn=%d N=%d)", ldc, ldxn, N);
+  return svlm_rmsnorm(C, norm_w, XN, M, N, eps, stream);
 }

@@ -362,16 +362,20 @@ class SvlmEngine:
         gu = torch.empty((T, 2 * tc.intermediate_size), dtype=BF16, device=dev)
         hm = torch.empty((T, tc.intermediate_size), dtype=BF16, device=dev)
         scale = 1.0 / math.sqrt(tc.head_dim)
+        n_layers = len(w.layers)
+        o.rmsnorm(x, w.layers[0]["ln1"], tc.rms_eps, out=xn)
         for li, lw in enumerate(w.layers):
-            o.rmsnorm(x, lw["ln1"], tc.rms_eps, out=xn)
             o.gemm(xn, lw["qkv_w"], bias=lw["qkv_b"], out=qkv)
             o.kv_append(qkv[:, qd:qd + kd], qkv[:, qd + kd:], c.pool, li, c.slot_of_dev, L_before, T)
             o.prefill_attn(qkv[:, :qd], c.pool, li, c.slot_of_dev, self.rope_cs, attn, T, L, tc.num_heads, scale)
-            o.gemm(attn, lw["o_w"], residual=x, out=x)
-            o.rmsnorm(x, lw["ln2"], tc.rms_eps, out=xn)
+            # the two residual-stream GEMMs hand their output row to the RMSNorm that follows inside their split-K reduce
+            o.gemm_norm(attn, lw["o_w"], lw["ln2"], tc.rms_eps, x, xn, residual=x)
             o.gemm(xn, lw["gu_w"], out=gu)
             o.silu_mul(gu, out=hm)
-            o.gemm(hm, lw["down_w"], residual=x, out=x)
+            if li + 1 < n_layers:
+                o.gemm_norm(hm, lw["down_w"], w.layers[li + 1]["ln1"], tc.rms_eps, x, xn, residual=x)
+            else:
+                o.gemm(hm, lw["down_w"], residual=x, out=x)
         last = x[T - 1:T].contiguous()
         o.rmsnorm(last, w.final_norm, tc.rms_eps, out=self.d_xn.view(1, H))
         o.gemv(self.d_xn, w.lm_head, out_f32=self.logits)

@@ -84,6 +84,27 @@ class HipOps:
                                       _ptr(out), out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _stream()), "svlm_gemm_bf16")
         return out
 
+    def gemm_norm(self, A, W, norm_w, eps, out, out_norm, bias=None, residual=None, act=ACT_NONE):
+        """out = epi(A @ W^T) as `gemm`; out_norm = RMSNorm(out) * norm_w, inside the split-K reduce when there is one."""
+        _req(A, BF16, "gemm_norm.A", 2); _req(W, BF16, "gemm_norm.W", 2); _req(out, BF16, "gemm_norm.out", 2)
+        _req(out_norm, BF16, "gemm_norm.out_norm", 2); _req(norm_w, BF16, "gemm_norm.norm_w", 1)
+        M, K = A.shape
+        N = W.shape[0]
+        assert W.shape[1] == K and tuple(out.shape) == (M, N) == tuple(out_norm.shape) and norm_w.numel() == N
+        assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and out_norm.stride(1) == 1
+        ldr = 0
+        if residual is not None:
+            _req(residual, BF16, "gemm_norm.residual", 2)
+            assert tuple(residual.shape) == (M, N) and residual.stride(1) == 1
+            ldr = residual.stride(0)
+        if bias is not None:
+            _req(bias, BF16, "gemm_norm.bias", 1)
+        ws = self._ws(A.device)
+        check(self.lib.svlm_gemm_bf16_norm(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out),
+                                           out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _ptr(norm_w), float(eps),
+                                           _ptr(out_norm), out_norm.stride(0), _stream()), "svlm_gemm_bf16_norm")
+        return out, out_norm
+
     def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=ACT_NONE):
         _req(x, BF16, "gemv.x"); _req(W, BF16, "gemv.W", 2)
         N, K = W.shape

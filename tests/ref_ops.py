@@ -38,6 +38,11 @@ class RefOps:
         out.copy_(y)
         return out
 
+    def gemm_norm(self, A, W, norm_w, eps, out, out_norm, bias=None, residual=None, act=0):
+        self.gemm(A, W, bias=bias, residual=residual, out=out, act=act)
+        self.rmsnorm(out, norm_w, eps, out=out_norm)
+        return out, out_norm
+
     def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=0):
         y = _act(F.linear(x.reshape(1, -1), W, bias)[0], act)
         if residual is not None:

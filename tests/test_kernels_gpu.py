@@ -91,6 +91,24 @@ def test_gemm_every_plan_is_numerically_the_same_op(ops, ref, bm, splits, monkey
     close(f"gemm plan bm{bm} s{splits}", got, want)
 
 
+@pytest.mark.parametrize("M,N,K", [(290, 1536, 8960), (290, 1536, 1536), (290, 3584, 18944), (33, 256, 512), (290, 17920, 1536)])
+def test_gemm_norm_fused_reduce(ops, ref, M, N, K):
+    """svlm_gemm_bf16_norm: residual-stream GEMM + the RMSNorm of its output rows (inside the split-K reduce when the plan
+    splits K, a second launch otherwise, e.g. the (33, 256, 512) and the 17920-wide cases) == GEMM then RMSNorm, in place."""
+    A, W, r_, g = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((M, N), 4), rnd((N,), 5, 0.1) + 1
+    x_c, xn_c = r_.clone(), torch.empty((M, N), dtype=BF16)
+    ref.gemm_norm(A, W, g, 1e-6, x_c, xn_c, residual=x_c)
+    x_g, xn_g = r_.clone().cuda(), torch.empty((M, N), dtype=BF16, device="cuda")
+    ops.gemm_norm(A.cuda(), W.cuda(), g.cuda(), 1e-6, x_g, xn_g, residual=x_g)
+    close("gemm_norm out", x_g, x_c)
+    close("gemm_norm norm", xn_g, xn_c, max_tol=2 ** -6)
+    # against the norm kernel applied to the GPU's own GEMM output only the fp32 summation order of the mean square differs
+    # (one workgroup per row here, one wave per row there): at most single bf16 roundings flip
+    want = ops.rmsnorm(x_g, g.cuda(), 1e-6, out=torch.empty_like(x_g))
+    d = (xn_g.float() - want.float()).abs()
+    assert float(d.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
+
+
 def test_gemm_inplace_residual(ops, ref):
     A, W, x = rnd((300, 256), 1), rnd((512, 256), 2, 0.05), rnd((300, 512), 3)
     want = ref.gemm(A, W, None, x)
