@@ -119,15 +119,19 @@ long long svlm_decode_attn_ws_bytes(int Hq, int max_len, int chunk);
 int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of, const void* rope_cs,
                               const int* len_dev, int len_add, void* out, void* ws, int Hq, int Hkv, int D, int n_slots,
                               int max_len, int chunk, float scale, void* stream);
-/* Prefill attention: q (T, q_stride) un-rotated rows for logical positions L-T..L-1 (their K/V already
- * appended), causal bottom-right aligned; out (T, o_stride); ws >= svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv)
+/* Prefill attention: q (T, q_stride) un-rotated rows for logical positions L-T..L-1, causal bottom-right aligned.
+ * Their un-rotated K/V rows are either already in the pool (k_new = v_new = NULL, after svlm_kv_append) or handed over as
+ * k_new / v_new (T, kv_new_stride) -- e.g. column slices of the fused QKV projection -- and APPENDED to their slots by the
+ * same launch that rotates the keys (StreamingCache.update, generate/streaming_cache.py:72-73).
+ * out (T, o_stride); ws >= svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv)
  * holds the rotated queries, this layer's rotated keys / gathered values in logical order and, when the
  * query tiles alone cannot fill the chip, the fp32 (O, m, l) partials of up to 8 key splits.
  * replaces: same lines at q_len = T. */
 long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv);
-int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_planes, const void* v_planes, const int* slot_of,
-                               const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D, int n_slots,
-                               float scale, void* ws, long long ws_bytes, void* stream);
+int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
+                               void* k_planes, void* v_planes, const int* slot_of, const void* rope_cs, void* out, int o_stride,
+                               int T, int L, int Hq, int Hkv, int D, int n_slots, float scale, void* ws, long long ws_bytes,
+                               void* stream);
 
 /* seen[id] = 1 for ids[0..n).  (input to the repetition penalty) */
 int svlm_mark_seen(const int* ids, int n, void* seen, int V, void* stream);

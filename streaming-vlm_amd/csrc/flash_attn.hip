@@ -314,7 +314,8 @@ static inline int prefill_splits(int T, int L, int Hq) {
 // K: gather + rotate; V: gather; Q: rotate.  D = 128; one thread per 16-B chunk.
 //   k_rot, v_lin: (Hkv, L, 128) in logical order;  q_rot: (T, Hq*128)
 __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restrict__ q, int q_stride,
-                                                          const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
+                                                          const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, int kv_new_stride,
+                                                          bf16_t* __restrict__ k_planes, bf16_t* __restrict__ v_planes,
                                                           const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs,
                                                           bf16_t* __restrict__ q_rot, bf16_t* __restrict__ k_rot,
                                                           bf16_t* __restrict__ v_lin, int T, int L, int Hq, int Hkv, int n_slots) {
@@ -322,11 +323,18 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
   const long nk = (long)Hkv * L * CPR, nq = (long)T * Hq * CPR;
   const long total = 2 * nk + nq;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    if (i >= nk && i < 2 * nk) {                      // V: plain gather
+    if (i >= nk && i < 2 * nk) {                      // V: plain gather (new rows: taken from the projection output and APPENDED)
       const long t = i - nk;
       const int c = (int)(t % CPR), j = (int)((t / CPR) % L), h = (int)(t / ((long)CPR * L));
-      *reinterpret_cast<u32x4_t*>(v_lin + ((size_t)h * L + j) * D + c * 8) =
-          *reinterpret_cast<const u32x4_t*>(v_planes + ((size_t)h * n_slots + slot_of[j]) * D + c * 8);
+      bf16_t* slot_p = v_planes + ((size_t)h * n_slots + slot_of[j]) * D + c * 8;
+      u32x4_t v;
+      if (v_new != nullptr && j >= L - T) {
+        v = *reinterpret_cast<const u32x4_t*>(v_new + (size_t)(j - (L - T)) * kv_new_stride + h * D + c * 8);
+        *reinterpret_cast<u32x4_t*>(slot_p) = v;     // StreamingCache.update (streaming_cache.py:72-73)
+      } else {
+        v = *reinterpret_cast<const u32x4_t*>(slot_p);
+      }
+      *reinterpret_cast<u32x4_t*>(v_lin + ((size_t)h * L + j) * D + c * 8) = v;
       continue;
     }
     const bf16_t* src;
@@ -335,7 +343,12 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
     if (i < nk) {
       c = (int)(i % CPR);
       const int j = (int)((i / CPR) % L), h = (int)(i / ((long)CPR * L));
-      src = k_planes + ((size_t)h * n_slots + slot_of[j]) * D;
+      bf16_t* slot_p = k_planes + ((size_t)h * n_slots + slot_of[j]) * D;
+      src = slot_p;
+      if (k_new != nullptr && j >= L - T) {           // new row: un-rotated K goes to its pool slot, the rotated copy to k_rot
+        src = k_new + (size_t)(j - (L - T)) * kv_new_stride + h * D;
+        *reinterpret_cast<u32x4_t*>(slot_p + c * 8) = *reinterpret_cast<const u32x4_t*>(src + c * 8);
+      }
       dst = k_rot + ((size_t)h * L + j) * D;
       pos = j;
     } else {
@@ -370,9 +383,12 @@ extern "C" long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv) {
 }
 
 // LLM prefill: q (T, Hq*128) un-rotated rows, pool planes of one layer, out (T, Hq*128).
-extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_planes, const void* v_planes, const int* slot_of,
+extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
+                                          void* k_planes, void* v_planes, const int* slot_of,
                                           const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D,
                                           int n_slots, float scale, void* ws, long long ws_bytes, void* stream) {
+  SVLM_CHECK_ARG((k_new == nullptr) == (v_new == nullptr) && (k_new == nullptr || (kv_new_stride % 8 == 0 && kv_new_stride >= Hkv * D)),
+                 "svlm_prefill_attn_ropeload: k_new / v_new come as a pair with a 16-B aligned row stride >= Hkv*D (stride %d)", kv_new_stride);
   SVLM_CHECK_ARG(D == 128, "svlm_prefill_attn_ropeload: head_dim %d unsupported (128 only)", D);
   SVLM_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "svlm_prefill_attn_ropeload: Hq=%d Hkv=%d", Hq, Hkv);
   SVLM_CHECK_ARG(T >= 0 && L >= T && n_slots > 0, "svlm_prefill_attn_ropeload: need 0 <= T=%d <= L=%d", T, L);
@@ -386,7 +402,8 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   const long total = (2L * Hkv * L + (long)T * Hq) * 16;
   int g = (int)((total + 255) / 256);
   g = g > 4096 ? 4096 : g;
-  rope_gather_kernel<<<g, 256, 0, st>>>((const bf16_t*)q, q_stride, (const bf16_t*)k_planes, (const bf16_t*)v_planes, slot_of,
+  rope_gather_kernel<<<g, 256, 0, st>>>((const bf16_t*)q, q_stride, (const bf16_t*)k_new, (const bf16_t*)v_new, kv_new_stride,
+                                       (bf16_t*)k_planes, (bf16_t*)v_planes, slot_of,
                                        (const bf16_t*)rope_cs, q_rot, k_rot, v_lin, T, L, Hq, Hkv, n_slots);
   int rc = svlm_check_launch("svlm_prefill_attn_ropeload(rope_gather)");
   if (rc) return rc;

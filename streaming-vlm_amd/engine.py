@@ -366,8 +366,9 @@ class SvlmEngine:
         o.rmsnorm(x, w.layers[0]["ln1"], tc.rms_eps, out=xn)
         for li, lw in enumerate(w.layers):
             o.gemm(xn, lw["qkv_w"], bias=lw["qkv_b"], out=qkv)
-            o.kv_append(qkv[:, qd:qd + kd], qkv[:, qd + kd:], c.pool, li, c.slot_of_dev, L_before, T)
-            o.prefill_attn(qkv[:, :qd], c.pool, li, c.slot_of_dev, self.rope_cs, attn, T, L, tc.num_heads, scale)
+            # the chunk's K/V rows go to their pool slots inside the launch that rotates and gathers the keys
+            o.prefill_attn(qkv[:, :qd], c.pool, li, c.slot_of_dev, self.rope_cs, attn, T, L, tc.num_heads, scale,
+                           k_new=qkv[:, qd:qd + kd], v_new=qkv[:, qd + kd:])
             # the two residual-stream GEMMs hand their output row to the RMSNorm that follows inside their split-K reduce
             o.gemm_norm(attn, lw["o_w"], lw["ln2"], tc.rms_eps, x, xn, residual=x)
             o.gemm(xn, lw["gu_w"], out=gu)

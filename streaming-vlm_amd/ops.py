@@ -290,7 +290,9 @@ class HipOps:
               "svlm_decode_attn_ropeload")
         return out
 
-    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale):
+    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale, k_new=None, v_new=None):
+        """k_new / v_new (T, Hkv*D) row views: the chunk's un-rotated K/V rows, appended to their slots by the same launch that
+        rotates the keys (otherwise they must already be in the pool, `kv_append`)."""
         _req(q, BF16, "prefill_attn.q", 2); _req(out, BF16, "prefill_attn.out", 2)
         _req(rope_cs, BF16, "prefill_attn.rope_cs", 2); _req(slot_of, torch.int32, "prefill_attn.slot_of", 1)
         _, _, Hkv, n_slots, D = pool.shape
@@ -303,9 +305,15 @@ class HipOps:
         if ws is None or ws.numel() * 2 < need:
             ws = torch.empty(max(need // 2, 1 << 20), dtype=BF16, device=q.device)
             self._gemm_ws[key] = ws
-        check(self.lib.svlm_prefill_attn_ropeload(_ptr(q), q.stride(0), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(rope_cs), _ptr(out),
-                                                  out.stride(0), T, L, Hq, Hkv, D, n_slots, float(scale), _ptr(ws), ws.numel() * 2,
-                                                  _stream()), "svlm_prefill_attn_ropeload")
+        kv_stride = 0
+        if k_new is not None or v_new is not None:
+            _req(k_new, BF16, "prefill_attn.k_new", 2); _req(v_new, BF16, "prefill_attn.v_new", 2)
+            assert k_new.shape[0] >= T and k_new.shape[1] == Hkv * D == v_new.shape[1] and k_new.stride(1) == 1 == v_new.stride(1)
+            assert k_new.stride(0) == v_new.stride(0)
+            kv_stride = k_new.stride(0)
+        check(self.lib.svlm_prefill_attn_ropeload(_ptr(q), q.stride(0), _ptr(k_new), _ptr(v_new), kv_stride, _ptr(kp), _ptr(vp),
+                                                  _ptr(slot_of), _ptr(rope_cs), _ptr(out), out.stride(0), T, L, Hq, Hkv, D, n_slots,
+                                                  float(scale), _ptr(ws), ws.numel() * 2, _stream()), "svlm_prefill_attn_ropeload")
         return out
 
     # ------------------------------------------------------------------ sampling

@@ -177,8 +177,10 @@ class RefOps:
         out.copy_(o.reshape(out.shape))
         return out
 
-    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale):
+    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale, k_new=None, v_new=None):
         D = pool.shape[-1]
+        if k_new is not None:
+            self.kv_append(k_new, v_new, pool, layer, slot_of, L - T, T)
         o = self._attend(q[:T].reshape(T, Hq, D).transpose(0, 1), pool, layer, slot_of, rope_cs, T, L, Hq, scale)
         out[:T] = o.transpose(0, 1).reshape(T, Hq * D)
         return out

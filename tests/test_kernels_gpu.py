@@ -287,6 +287,26 @@ def test_prefill_attn(ops, ref, Hq, Hkv, T, L):
     close(f"prefill_attn Hq{Hq} Hkv{Hkv} T{T} L{L}", out, want, max_tol=2 ** -6, mean_tol=1e-3)
 
 
+def test_prefill_attn_appends_the_new_rows(ops, ref):
+    """k_new / v_new handed to the prefill attention are written to their pool slots (== svlm_kv_append) by the launch that
+    rotates the keys, and the result equals append-then-attend."""
+    Hq, Hkv, T, L = 12, 2, 70, 333
+    cap = 384
+    pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 21)
+    q, kn, vn = rnd((T, Hq * 128), 5), rnd((T, Hkv * 128), 6), rnd((T, Hkv * 128), 7)
+    scale = 1 / math.sqrt(128)
+    pool_c = pool.clone()
+    want = ref.prefill_attn(q, pool_c, 0, slot_of, rope, torch.empty((T, Hq * 128), dtype=BF16), T, L, Hq, scale, k_new=kn, v_new=vn)
+    # hand the rows over as column slices of one fused buffer, like the engine does
+    fused = torch.cat([q, kn, vn], 1).cuda()
+    pool_g = pool.clone().cuda()
+    out = torch.empty((T, Hq * 128), dtype=BF16, device="cuda")
+    ops.prefill_attn(fused[:, :Hq * 128], pool_g, 0, slot_of.cuda(), rope.cuda(), out, T, L, Hq, scale,
+                     k_new=fused[:, Hq * 128:(Hq + Hkv) * 128], v_new=fused[:, (Hq + Hkv) * 128:])
+    close("prefill_attn with append", out, want, max_tol=2 ** -6, mean_tol=1e-3)
+    assert torch.equal(pool_g.cpu(), pool_c), "pool rows after the fused append differ from svlm_kv_append semantics"
+
+
 def test_prefill_matches_decode_on_last_row(ops):
     """Size-independent property: the last prefill row equals a decode step over the same cache."""
     Hq, Hkv, T, L = 12, 2, 64, 1500
