@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SVLM_LIB_PATH") or os.path.join(_HERE, "libsvlm_hip.so")      # override: diagnostic builds (tools/)
 
 SVLM_OK = 0
-ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF, ACT_SILU, ACT_SWIGLU = 0, 1, 2, 3, 4
 
 
 class SvlmError(RuntimeError):

@@ -107,6 +107,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define SVLM_ACT_QUICK_GELU 1
 #define SVLM_ACT_GELU_ERF 2
 #define SVLM_ACT_SILU 3
+#define SVLM_ACT_SWIGLU 4      // GEMM only: W = [gate rows; up rows], C[m, n] = silu(gate_n . a_m) * (up_n . a_m)
 
 // y is the bf16-rounded linear output (as float); returns the activation with the eager
 // module's intermediate roundings (each torch op rounds to bf16).

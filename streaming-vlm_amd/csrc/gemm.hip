@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
     tm = local % gm;
     if (tn >= gn) return;
   }
-  const int m0 = tm * BM, n0 = tn * GEMM_BN;
+  const bool swiglu = act == SVLM_ACT_SWIGLU;     // 64 output columns per tile: gate | up halves of the 128 tile columns
+  const int m0 = tm * BM, n0 = tn * (swiglu ? GEMM_BN / 2 : GEMM_BN);
   const int k_begin = split * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
   const int nk = (k_end - k_begin) / GEMM_BK;    // K % 64 == 0 and k_per_split % 64 == 0
@@ -249,7 +250,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int i = 0; i < W_INST; ++i) {
     const int row = (wave * W_INST + i) * 8 + rsub;
-    w_src[i] = W + (size_t)min(n0 + row, N - 1) * ldw + k_begin + ((ppos ^ (row & 7)) * 8);
+    // SwiGLU pairing: tile rows 0..63 are gate rows n0.., tile rows 64..127 the matching up rows N + n0.. (N = output columns)
+    const int wrow = swiglu ? (row < 64 ? min(n0 + row, N - 1) : N + min(n0 + row - 64, N - 1)) : min(n0 + row, N - 1);
+    w_src[i] = W + (size_t)wrow * ldw + k_begin + ((ppos ^ (row & 7)) * 8);
   }
   auto issue = [&](int kt, int stage) {
     unsigned char* sa = smem + stage * STAGE_B;
@@ -318,6 +321,43 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
   }
 #endif
 
+  if (swiglu) {
+    // the up half (waves wn = 1) hands its bf16-rounded values to the gate half through the staging LDS, which is free now
+    float* U = reinterpret_cast<float*>(smem);                       // [BM][64]
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wn == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4_t u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] = rbf(acc[i][j][r]);
+          *reinterpret_cast<f32x4_t*>(U + (wm * 16 * TM + i * 16 + fr) * 64 + j * 16 + fq * 4) = u;
+        }
+    }
+    __syncthreads();
+    if (wn == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * 16 * TM + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + j * 16 + fq * 4;
+          if (m >= M || n >= N) continue;
+          const f32x4_t u = *reinterpret_cast<const f32x4_t*>(U + (wm * 16 * TM + i * 16 + fr) * 64 + j * 16 + fq * 4);
+          float h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = apply_act(rbf(acc[i][j][r]), SVLM_ACT_SILU) * u[r];
+          u32x2_t o;
+          o[0] = pack2(h[0], h[1]);
+          o[1] = pack2(h[2], h[3]);
+          *reinterpret_cast<u32x2_t*>(C + (size_t)m * ldc + n) = o;
+        }
+      }
+    }
+    return;
+  }
   // epilogue: lane holds m = fr (column of D), n = 4*fq + r (rows of D)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -475,10 +515,13 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   SVLM_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0),
                  "svlm_gemm_bf16: leading dims must keep 16-B row alignment (lda=%d ldw=%d ldc=%d ldr=%d)", lda, ldw, ldc, ldr);
   SVLM_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "svlm_gemm_bf16: leading dim smaller than row length");
-  SVLM_CHECK_ARG(act >= 0 && act <= 3, "svlm_gemm_bf16: unknown activation %d", act);
+  SVLM_CHECK_ARG(act >= 0 && act <= 4, "svlm_gemm_bf16: unknown activation %d", act);
+  const bool swiglu = act == SVLM_ACT_SWIGLU;
+  SVLM_CHECK_ARG(!swiglu || (bias == nullptr && residual == nullptr && norm_w == nullptr && K % GEMM_BK == 0 && N % 8 == 0),
+                 "svlm_gemm_bf16: SVLM_ACT_SWIGLU takes W = [gate; up] without bias / residual and K %% 64 == 0 (K=%d)", K);
   if (M == 0) return SVLM_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int gn = (N + GEMM_BN - 1) / GEMM_BN;
+  const int gn = swiglu ? (N + GEMM_BN / 2 - 1) / (GEMM_BN / 2) : (N + GEMM_BN - 1) / GEMM_BN;      // SwiGLU: 64 output columns per tile
   // ---- tile height and K-split from a small cost model.  The path's GEMMs are one or two "rounds" of resident
   // workgroups, so quantisation decides: cost = rounds x K-steps per workgroup x step cost (+ slab traffic).
   // Resident workgroups per CU: LDS 2 x (BM+128) x 128 B -> 48 KB (BM=64): 3, 64 KB (BM=128): 2.
@@ -535,6 +578,10 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
     if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
     if ((long long)best_splits * M * N * 4 > ws_bytes || ws == nullptr || K < 1024) best_splits = 1;
   }
+  if (swiglu) {                       // one K pass (the pairing happens in the epilogue), register budget of the 64/128-row tiles
+    best_splits = 1;
+    if (best_bm > 128) best_bm = 128;
+  }
   const bool small = best_bm == 64;
   const int bm = best_bm;
   const int gm = (M + bm - 1) / bm;
@@ -560,8 +607,8 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
     attr_done = true;
   }
   const bool dma = (K % GEMM_BK == 0) && getenv("SVLM_GEMM_NO_DMA") == nullptr;
-  if (!dma && (bm == 192 || bm == 320)) {
-    svlm_set_error("svlm_gemm_bf16: tall tiles need K %% 64 == 0");
+  if (!dma && (bm == 192 || bm == 320 || swiglu)) {
+    svlm_set_error("svlm_gemm_bf16: tall tiles and SVLM_ACT_SWIGLU run on the LDS-DMA kernel only (K %% 64 == 0, SVLM_GEMM_NO_DMA unset)");
     return SVLM_EINVAL;
   }
   if (dma) {

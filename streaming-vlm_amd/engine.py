@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
-from ._lib import ACT_GELU_ERF, ACT_QUICK_GELU
+from ._lib import ACT_GELU_ERF, ACT_QUICK_GELU, ACT_SWIGLU
 from .config import ModelConfig
 from .kv_pool import KVPool
 from .positions import rope_index_1d, rope_index_qwen2, rope_index_qwen2_5
@@ -371,8 +371,11 @@ class SvlmEngine:
                            k_new=qkv[:, qd:qd + kd], v_new=qkv[:, qd + kd:])
             # the two residual-stream GEMMs hand their output row to the RMSNorm that follows inside their split-K reduce
             o.gemm_norm(attn, lw["o_w"], lw["ln2"], tc.rms_eps, x, xn, residual=x)
-            o.gemm(xn, lw["gu_w"], out=gu)
-            o.silu_mul(gu, out=hm)
+            if H % 64 == 0:            # gate and up columns paired inside the GEMM tile: SwiGLU in its epilogue, no (T, 2I) round trip
+                o.gemm(xn, lw["gu_w"], out=hm, act=ACT_SWIGLU)
+            else:
+                o.gemm(xn, lw["gu_w"], out=gu)
+                o.silu_mul(gu, out=hm)
             if li + 1 < n_layers:
                 o.gemm_norm(hm, lw["down_w"], w.layers[li + 1]["ln1"], tc.rms_eps, x, xn, residual=x)
             else:

@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, check
+from ._lib import ACT_NONE, ACT_SWIGLU, check
 
 BF16 = torch.bfloat16
 
@@ -66,6 +66,10 @@ class HipOps:
         N, K2 = W.shape
         if K != K2:
             raise _lib.SvlmError(f"gemm: A is {tuple(A.shape)} but W is {tuple(W.shape)}")
+        if act == ACT_SWIGLU:          # W = [gate rows; up rows]: the output has half as many columns
+            if N % 2 or bias is not None or residual is not None:
+                raise _lib.SvlmError("gemm: ACT_SWIGLU takes W = [gate; up] (even row count) without bias / residual")
+            N //= 2
         if out is None:
             out = torch.empty((M, N), dtype=BF16, device=A.device)
         _req(out, BF16, "gemm.out", 2)

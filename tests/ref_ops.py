@@ -30,6 +30,14 @@ class RefOps:
     name = "ref-cpu"
 
     def gemm(self, A, W, bias=None, residual=None, out=None, act=0):
+        if act == 4:          # ACT_SWIGLU: W = [gate; up]
+            gu = F.linear(A, W)
+            I = gu.shape[1] // 2
+            y = F.silu(gu[:, :I]) * gu[:, I:]
+            if out is None:
+                return y
+            out.copy_(y)
+            return out
         y = _act(F.linear(A, W, bias), act)
         if residual is not None:
             y = residual + y

@@ -109,6 +109,28 @@ def test_gemm_norm_fused_reduce(ops, ref, M, N, K):
     assert float(d.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
 
 
+@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64)])
+def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
+    """ACT_SWIGLU: W = [gate rows; up rows]; every tile pairs 64 gate with the 64 matching up columns and applies
+    bf16(bf16(silu(g)) * u) in its epilogue == GEMM to (M, 2I) followed by svlm_silu_mul, for both tile heights."""
+    A, W = rnd((M, K), 1), rnd((2 * I, K), 2, 0.05)
+    want = ref.gemm(A, W, act=4)
+    gu = ops.gemm(A.cuda(), W.cuda())
+    sep = ops.silu_mul(gu, out=torch.empty((M, I), dtype=BF16, device="cuda"))
+    for bm in (None, 64, 128):
+        if bm is None:
+            monkeypatch.delenv("SVLM_GEMM_BM", raising=False)
+        else:
+            monkeypatch.setenv("SVLM_GEMM_BM", str(bm))
+        got = ops.gemm(A.cuda(), W.cuda(), act=4)
+        assert got.shape == (M, I)
+        close(f"gemm swiglu bm={bm}", got, want)
+        assert torch.equal(got, sep) or bm is not None, "default plan: same K order as the separate launches -> same bits"
+    from streaming_vlm_amd._lib import SvlmError as _Err
+    with pytest.raises(_Err):
+        ops.gemm(A.cuda(), W.cuda(), bias=rnd((2 * I,), 3).cuda(), act=4)
+
+
 def test_gemm_inplace_residual(ops, ref):
     A, W, x = rnd((300, 256), 1), rnd((512, 256), 2, 0.05), rnd((300, 512), 3)
     want = ref.gemm(A, W, None, x)
