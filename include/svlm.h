@@ -39,7 +39,7 @@ extern "C" {
 #define SVLM_ACT_GELU_ERF 2   /* nn.GELU(), PatchMerger (qwen2/vision_forward.py:80) */
 #define SVLM_ACT_SILU 3
 #define SVLM_ACT_SWIGLU 4      /* svlm_gemm_bf16 only: W = [gate rows; up rows] (2N x K), C (M x N) = bf16(bf16(silu(gate)) * up):
-                                  Qwen2MLP's act_fn(gate_proj(x)) * up_proj(x) (qwen2/language_forward.py:201); no bias/residual */
+                                  Qwen2MLP's act_fn(gate_proj(x)) * up_proj(x) (qwen2/language_forward.py:201); bias, if any, is [gate; up] too; no residual */
 
 int svlm_abi_version(void);
 const char* svlm_last_error(void); /* [host] */

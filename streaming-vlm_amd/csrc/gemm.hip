@@ -331,8 +331,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           f32x4_t u;
+          const int nb = min(n0 + j * 16 + fq * 4, N - 4);
+          float ub[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bias) {                                        // up bias = second half of the [gate; up] bias vector
+            const u32x2_t bv = *reinterpret_cast<const u32x2_t*>(bias + N + nb);
+            ub[0] = lo_bf(bv[0]); ub[1] = hi_bf(bv[0]); ub[2] = lo_bf(bv[1]); ub[3] = hi_bf(bv[1]);
+          }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u[r] = rbf(acc[i][j][r]);
+          for (int r = 0; r < 4; ++r) u[r] = rbf(acc[i][j][r] + ub[r]);
           *reinterpret_cast<f32x4_t*>(U + (wm * 16 * TM + i * 16 + fr) * 64 + j * 16 + fq * 4) = u;
         }
     }
@@ -346,9 +352,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
           const int n = n0 + j * 16 + fq * 4;
           if (m >= M || n >= N) continue;
           const f32x4_t u = *reinterpret_cast<const f32x4_t*>(U + (wm * 16 * TM + i * 16 + fr) * 64 + j * 16 + fq * 4);
-          float h[4];
+          float h[4], gb[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bias) {
+            const u32x2_t bv = *reinterpret_cast<const u32x2_t*>(bias + n);
+            gb[0] = lo_bf(bv[0]); gb[1] = hi_bf(bv[0]); gb[2] = lo_bf(bv[1]); gb[3] = hi_bf(bv[1]);
+          }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = apply_act(rbf(acc[i][j][r]), SVLM_ACT_SILU) * u[r];
+          for (int r = 0; r < 4; ++r) h[r] = apply_act(rbf(acc[i][j][r] + gb[r]), SVLM_ACT_SILU) * u[r];
           u32x2_t o;
           o[0] = pack2(h[0], h[1]);
           o[1] = pack2(h[2], h[3]);
@@ -517,8 +527,8 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   SVLM_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "svlm_gemm_bf16: leading dim smaller than row length");
   SVLM_CHECK_ARG(act >= 0 && act <= 4, "svlm_gemm_bf16: unknown activation %d", act);
   const bool swiglu = act == SVLM_ACT_SWIGLU;
-  SVLM_CHECK_ARG(!swiglu || (bias == nullptr && residual == nullptr && norm_w == nullptr && K % GEMM_BK == 0 && N % 8 == 0),
-                 "svlm_gemm_bf16: SVLM_ACT_SWIGLU takes W = [gate; up] without bias / residual and K %% 64 == 0 (K=%d)", K);
+  SVLM_CHECK_ARG(!swiglu || (residual == nullptr && norm_w == nullptr && K % GEMM_BK == 0 && N % 8 == 0),
+                 "svlm_gemm_bf16: SVLM_ACT_SWIGLU takes W = [gate; up] (bias = [gate; up] too) without residual, K %% 64 == 0 and N %% 8 == 0 (N=%d K=%d)", N, K);
   if (M == 0) return SVLM_OK;
   hipStream_t st = (hipStream_t)stream;
   const int gn = swiglu ? (N + GEMM_BN / 2 - 1) / (GEMM_BN / 2) : (N + GEMM_BN - 1) / GEMM_BN;      // SwiGLU: 64 output columns per tile

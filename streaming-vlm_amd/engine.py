@@ -132,8 +132,11 @@ class _VitRun:
                 o.vit_attn(qkv[row:row + n * ln], n, ln, Hh, d, scale, out=a[row:row + n * ln])
             o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
             o.rmsnorm(x, bw["n2w"], 1e-6, out=h)
-            o.gemm(h, bw["gu_w"], bias=bw["gu_b"], out=self.f)
-            o.silu_mul(self.f, out=self.g)
+            if E % 64 == 0:            # SwiGLU (with its biases) in the gate/up GEMM's epilogue
+                o.gemm(h, bw["gu_w"], bias=bw["gu_b"], out=self.g, act=ACT_SWIGLU)
+            else:
+                o.gemm(h, bw["gu_w"], bias=bw["gu_b"], out=self.f)
+                o.silu_mul(self.f, out=self.g)
             o.gemm(self.g, bw["down_w"], bias=bw["down_b"], residual=x, out=x)
 
     def blocks(self, lo: int, hi: int):

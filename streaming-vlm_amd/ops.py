@@ -67,8 +67,8 @@ class HipOps:
         if K != K2:
             raise _lib.SvlmError(f"gemm: A is {tuple(A.shape)} but W is {tuple(W.shape)}")
         if act == ACT_SWIGLU:          # W = [gate rows; up rows]: the output has half as many columns
-            if N % 2 or bias is not None or residual is not None:
-                raise _lib.SvlmError("gemm: ACT_SWIGLU takes W = [gate; up] (even row count) without bias / residual")
+            if N % 2 or residual is not None or (bias is not None and bias.numel() != N):
+                raise _lib.SvlmError("gemm: ACT_SWIGLU takes W = [gate; up] (even row count), bias = [gate; up], no residual")
             N //= 2
         if out is None:
             out = torch.empty((M, N), dtype=BF16, device=A.device)
@@ -77,7 +77,7 @@ class HipOps:
             raise _lib.SvlmError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
         if bias is not None:
             _req(bias, BF16, "gemm.bias", 1)
-            assert bias.numel() == N
+            assert bias.numel() == (2 * N if act == ACT_SWIGLU else N)
         ldr = 0
         if residual is not None:
             _req(residual, BF16, "gemm.residual", 2)

@@ -31,7 +31,7 @@ class RefOps:
 
     def gemm(self, A, W, bias=None, residual=None, out=None, act=0):
         if act == 4:          # ACT_SWIGLU: W = [gate; up]
-            gu = F.linear(A, W)
+            gu = F.linear(A, W, bias)
             I = gu.shape[1] // 2
             y = F.silu(gu[:, :I]) * gu[:, I:]
             if out is None:

@@ -126,9 +126,12 @@ def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
         assert got.shape == (M, I)
         close(f"gemm swiglu bm={bm}", got, want)
         assert torch.equal(got, sep) or bm is not None, "default plan: same K order as the separate launches -> same bits"
+    # with the [gate; up] bias of the Qwen2.5 vision MLP
+    b = rnd((2 * I,), 3, 0.2)
+    close("gemm swiglu + bias", ops.gemm(A.cuda(), W.cuda(), bias=b.cuda(), act=4), ref.gemm(A, W, bias=b, act=4))
     from streaming_vlm_amd._lib import SvlmError as _Err
     with pytest.raises(_Err):
-        ops.gemm(A.cuda(), W.cuda(), bias=rnd((2 * I,), 3).cuda(), act=4)
+        ops.gemm(A.cuda(), W.cuda(), residual=rnd((M, I), 4).cuda(), act=4)
 
 
 def test_gemm_inplace_residual(ops, ref):
