@@ -51,13 +51,14 @@ int svlm_device_cus(void);
  * qwen2/language_forward.py:80-82,161,201 (prefill rows). */
 int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                    void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream);
-/* svlm_gemm_bf16 followed by XN[m,:] = norm_w * bf16(C[m,:] * rsqrt(mean(C[m,:]^2) + eps)) (Qwen2RMSNorm of the GEMM's output
- * rows).  When the GEMM runs split-K the norm is computed inside the reduce launch; otherwise it is a second launch.
+/* svlm_gemm_bf16 followed by the norm of the GEMM's output rows: norm_b == NULL: XN[m,:] = norm_w * bf16(C[m,:] * rsqrt(mean(C^2) + eps))
+ * (Qwen2RMSNorm); else XN[m,:] = bf16((C[m,:] - mean) * rstd * norm_w + norm_b) (nn.LayerNorm, the ViT's norm1 / norm2).
+ * When the GEMM runs split-K the norm is computed inside the reduce launch; otherwise it is a second launch.
  * replaces: o_proj + residual -> post_attention_layernorm, down_proj + residual -> next input_layernorm
- * (qwen2/language_forward.py:161,195-200,183). */
+ * (qwen2/language_forward.py:161,195-200,183); ViT proj / fc2 + residual -> norm2 / next norm1 (qwen2/vision_forward.py:43-49). */
 int svlm_gemm_bf16_norm(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                         void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, const void* norm_w,
-                        float eps, void* XN, int ldxn, void* stream);
+                        const void* norm_b, float eps, void* XN, int ldxn, void* stream);
 
 /* y[N] = same epilogue for one row x[K] (decode step); y (bf16) and/or y_f32 (fp32 copy of the
  * bf16-rounded value: the `.float()` of streaming_generate_qwen.py:73) may be NULL.

@@ -440,8 +440,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const float* __restrict__ partial, int splits,
                                                                       const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
                                                                       bf16_t* C, int ldc, int M, int N, int act,
-                                                                      const bf16_t* __restrict__ norm_w, float eps, bf16_t* __restrict__ XN, int ldxn) {
-  // one workgroup per row, 8 columns per thread and pass: all slab loads of a thread are independent and issued together
+                                                                      const bf16_t* __restrict__ norm_w, const bf16_t* __restrict__ norm_b,
+                                                                      float eps, bf16_t* __restrict__ XN, int ldxn) {
+  // one workgroup per row, 8 columns per thread and pass: all slab loads of a thread are independent and issued together.
+  // norm_b == nullptr: RMSNorm (Qwen2RMSNorm); else LayerNorm with bias (the ViT's norm1 / norm2, one rounding at the end).
   const int m = blockIdx.x, tid = threadIdx.x;
   const size_t slab = (size_t)M * N;
   float y[RN_IT][8];
@@ -480,7 +482,44 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const floa
       for (int i = 0; i < 8; ++i) ss += y[it][i] * y[it][i];
     }
   }
-  __shared__ float red[4];
+  __shared__ float red[4], red2[4];
+  if (norm_b != nullptr) {                  // LayerNorm: mean first, then the centred second moment (as layernorm_kernel does)
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < RN_IT; ++it)
+      if (it * 2048 + tid * 8 < N) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s1 += y[it][i];
+      }
+    s1 = wave_sum(s1);
+    if ((tid & 63) == 0) red[tid >> 6] = s1;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)N;
+    float s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < RN_IT; ++it)
+      if (it * 2048 + tid * 8 < N) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = y[it][i] - mean; s2 += d * d; }
+      }
+    s2 = wave_sum(s2);
+    if ((tid & 63) == 0) red2[tid >> 6] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf((red2[0] + red2[1] + red2[2] + red2[3]) / (float)N + eps);
+#pragma unroll
+    for (int it = 0; it < RN_IT; ++it) {
+      const int n = it * 2048 + tid * 8;
+      if (n < N) {
+        float g[8], h[8], f[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(norm_w + n), g);
+        unpack8(*reinterpret_cast<const u32x4_t*>(norm_b + n), h);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (y[it][i] - mean) * rstd * g[i] + h[i];
+        *reinterpret_cast<u32x4_t*>(XN + (size_t)m * ldxn + n) = pack8(f);
+      }
+    }
+    return;
+  }
   ss = wave_sum(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
   __syncthreads();
@@ -499,27 +538,28 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const floa
 }
 
 extern "C" int svlm_rmsnorm(const void* x, const void* w, void* y, int rows, int cols, float eps, void* stream);
+extern "C" int svlm_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, void* stream);
 
 static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                      void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream,
-                     const void* norm_w, float eps, void* XN, int ldxn);
+                     const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn);
 
 extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                               void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream) {
-  return gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, stream, nullptr, 0.f, nullptr, 0);
+  return gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, stream, nullptr, nullptr, 0.f, nullptr, 0);
 }
 
 extern "C" int svlm_gemm_bf16_norm(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                                    void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
-                                   const void* norm_w, float eps, void* XN, int ldxn, void* stream) {
+                                   const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream) {
   SVLM_CHECK_ARG(norm_w != nullptr && XN != nullptr && N % 8 == 0 && ldc % 8 == 0 && ldxn % 8 == 0 && ldxn >= N && eps > 0.f,
                  "svlm_gemm_bf16_norm: needs a norm weight, an output with 16-B aligned rows and N %% 8 == 0 (N=%d ldc=%d ldxn=%d)", N, ldc, ldxn);
-  return gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, stream, norm_w, eps, XN, ldxn);
+  return gemm_impl(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, stream, norm_w, norm_b, eps, XN, ldxn);
 }
 
 static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                      void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream,
-                     const void* norm_w, float eps, void* XN, int ldxn) {
+                     const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn) {
   SVLM_CHECK_ARG(M >= 0 && N > 0 && K > 0, "svlm_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
   SVLM_CHECK_ARG(K % 8 == 0 && N % 4 == 0, "svlm_gemm_bf16: K=%d must be a multiple of 8 and N=%d of 4", K, N);
   SVLM_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0),
@@ -566,6 +606,8 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       {5, 2048, 2048, 64, 3},      // 3B o_proj: 14.4 vs 15.6
       {5, 2048, 11008, 64, 4},     // 3B down_proj: 33.3 vs 43.2
       {16, 1280, 5120, 128, 3},    // ViT fc2 (1024 patches): 31.3 vs 35.0
+      {16, 1280, 1280, 128, 3},    // ViT proj: 16.7 vs 15.4 unsplit, but the split-K reduce then carries the LayerNorm / RMSNorm that follows
+                                   // (svlm_gemm_bf16_norm), which costs a 5 us launch of its own otherwise
       {16, 1280, 3424, 128, 3},    // Qwen2.5 ViT down_proj: 28.7 vs 31.2
       {4, 5120, 5120, 128, 3},     // merger mlp.0 (256 merged tokens): 30.1 vs 37.8
       {4, 1536, 5120, 64, 5},      // merger mlp.2 -> 2B: 17.0 vs 21.3
@@ -673,7 +715,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   if (rc) return rc;
   if (splits > 1 && norm_w != nullptr && N <= 2048 * RN_IT) {      // reduce + RMSNorm of the reduced row in one launch
     gemm_splitk_reduce_norm_kernel<<<M, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C,
-                                                                ldc, M, N, act, (const bf16_t*)norm_w, eps, (bf16_t*)XN, ldxn);
+                                                                ldc, M, N, act, (const bf16_t*)norm_w, (const bf16_t*)norm_b, eps, (bf16_t*)XN, ldxn);
     return svlm_check_launch("svlm_gemm_bf16_norm(split-K reduce + norm)");
   }
   if (splits > 1) {
@@ -686,5 +728,5 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   }
   if (norm_w == nullptr) return SVLM_OK;
   SVLM_CHECK_ARG(ldc == N && ldxn == N, "svlm_gemm_bf16_norm: the unfused norm needs contiguous rows (ldc=%d ldxn=%d N=%d)", ldc, ldxn, N);
-  return svlm_rmsnorm(C, norm_w, XN, M, N, eps, stream);
+  return norm_b ? svlm_layernorm(C, norm_w, norm_b, XN, M, N, eps, stream) : svlm_rmsnorm(C, norm_w, XN, M, N, eps, stream);
 }

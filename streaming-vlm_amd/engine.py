@@ -102,6 +102,7 @@ class _VitRun:
         self.qkv = torch.empty((N, 3 * E), dtype=BF16, device=eng.device)
         self.a = torch.empty((N, E), dtype=BF16, device=eng.device)
         self.q25 = vc.arch == "qwen2_5"
+        self._h_is_norm1 = False
         if self.q25:
             # window order (qwen2_5/vision_forward.py:65-83): groups of merge^2 patches are gathered so that every
             # attention window is one contiguous run of rows; the rotary tables follow the same permutation
@@ -123,21 +124,28 @@ class _VitRun:
         Hh, d, E = vc.num_heads, vc.head_dim, vc.embed_dim
         scale = 1.0 / math.sqrt(d)
         x, h, qkv, a = self.x, self.h, self.qkv, self.a
+        blocks = self.eng.w.vit
+        if lo < hi and not self._h_is_norm1:
+            o.rmsnorm(x, blocks[lo]["n1w"], 1e-6, out=h)
         for bi in range(lo, hi):
-            bw = self.eng.w.vit[bi]
-            o.rmsnorm(x, bw["n1w"], 1e-6, out=h)
+            bw = blocks[bi]
             o.gemm(h, bw["qkv_w"], bias=bw["qkv_b"], out=qkv)
             o.vit_rope(qkv, self.cosT, self.sinT, Hh, d)
             for row, n, ln in (self.full_runs if bi in vc.fullatt_block_indexes else self.win_runs):
                 o.vit_attn(qkv[row:row + n * ln], n, ln, Hh, d, scale, out=a[row:row + n * ln])
-            o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
-            o.rmsnorm(x, bw["n2w"], 1e-6, out=h)
+            # proj / down hand their output row to the RMSNorm that follows (inside their split-K reduce)
+            o.gemm_norm(a, bw["proj_w"], bw["n2w"], 1e-6, x, h, bias=bw["proj_b"], residual=x)
             if E % 64 == 0:            # SwiGLU (with its biases) in the gate/up GEMM's epilogue
                 o.gemm(h, bw["gu_w"], bias=bw["gu_b"], out=self.g, act=ACT_SWIGLU)
             else:
                 o.gemm(h, bw["gu_w"], bias=bw["gu_b"], out=self.f)
                 o.silu_mul(self.f, out=self.g)
-            o.gemm(self.g, bw["down_w"], bias=bw["down_b"], residual=x, out=x)
+            if bi + 1 < len(blocks):
+                o.gemm_norm(self.g, bw["down_w"], blocks[bi + 1]["n1w"], 1e-6, x, h, bias=bw["down_b"], residual=x)
+            else:
+                o.gemm(self.g, bw["down_w"], bias=bw["down_b"], residual=x, out=x)
+        if lo < hi:
+            self._h_is_norm1 = hi < len(blocks)
 
     def blocks(self, lo: int, hi: int):
         if self.q25:
@@ -146,15 +154,24 @@ class _VitRun:
         Hh, d = vc.num_heads, vc.head_dim
         scale = 1.0 / math.sqrt(d)
         x, h, qkv, a, f = self.x, self.h, self.qkv, self.a, self.f
-        for bw in self.eng.w.vit[lo:hi]:
-            o.layernorm(x, bw["n1w"], bw["n1b"], 1e-6, out=h)
+        blocks = self.eng.w.vit
+        if lo < hi and not self._h_is_norm1:
+            o.layernorm(x, blocks[lo]["n1w"], blocks[lo]["n1b"], 1e-6, out=h)
+        for bi in range(lo, hi):
+            bw = blocks[bi]
             o.gemm(h, bw["qkv_w"], bias=bw["qkv_b"], out=qkv)
             o.vit_rope(qkv, self.cosT, self.sinT, Hh, d)
             o.vit_attn(qkv, self.n_seq, self.seq_len, Hh, d, scale, out=a)
-            o.gemm(a, bw["proj_w"], bias=bw["proj_b"], residual=x, out=x)
-            o.layernorm(x, bw["n2w"], bw["n2b"], 1e-6, out=h)
+            # proj / fc2 hand their output row to the LayerNorm that follows (inside their split-K reduce when there is one)
+            o.gemm_norm(a, bw["proj_w"], bw["n2w"], 1e-6, x, h, bias=bw["proj_b"], residual=x, norm_b=bw["n2b"])
             o.gemm(h, bw["fc1_w"], bias=bw["fc1_b"], out=f, act=ACT_QUICK_GELU)
-            o.gemm(f, bw["fc2_w"], bias=bw["fc2_b"], residual=x, out=x)
+            if bi + 1 < len(blocks):
+                nb = blocks[bi + 1]
+                o.gemm_norm(f, bw["fc2_w"], nb["n1w"], 1e-6, x, h, bias=bw["fc2_b"], residual=x, norm_b=nb["n1b"])
+            else:
+                o.gemm(f, bw["fc2_w"], bias=bw["fc2_b"], residual=x, out=x)
+        if lo < hi:
+            self._h_is_norm1 = hi < len(blocks)    # h already holds norm1 of the next block (for a resumed pass)
 
     def finish(self):
         o, vc, mg = self.eng.ops, self.eng.cfg.vision, self.eng.w.merger

@@ -88,8 +88,9 @@ class HipOps:
                                       _ptr(out), out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _stream()), "svlm_gemm_bf16")
         return out
 
-    def gemm_norm(self, A, W, norm_w, eps, out, out_norm, bias=None, residual=None, act=ACT_NONE):
-        """out = epi(A @ W^T) as `gemm`; out_norm = RMSNorm(out) * norm_w, inside the split-K reduce when there is one."""
+    def gemm_norm(self, A, W, norm_w, eps, out, out_norm, bias=None, residual=None, act=ACT_NONE, norm_b=None):
+        """out = epi(A @ W^T) as `gemm`; out_norm = RMSNorm(out) * norm_w (norm_b None) or LayerNorm(out; norm_w, norm_b), inside
+        the split-K reduce when there is one."""
         _req(A, BF16, "gemm_norm.A", 2); _req(W, BF16, "gemm_norm.W", 2); _req(out, BF16, "gemm_norm.out", 2)
         _req(out_norm, BF16, "gemm_norm.out_norm", 2); _req(norm_w, BF16, "gemm_norm.norm_w", 1)
         M, K = A.shape
@@ -105,7 +106,7 @@ class HipOps:
             _req(bias, BF16, "gemm_norm.bias", 1)
         ws = self._ws(A.device)
         check(self.lib.svlm_gemm_bf16_norm(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), _ptr(residual), ldr, _ptr(out),
-                                           out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _ptr(norm_w), float(eps),
+                                           out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _ptr(norm_w), _ptr(norm_b), float(eps),
                                            _ptr(out_norm), out_norm.stride(0), _stream()), "svlm_gemm_bf16_norm")
         return out, out_norm
 

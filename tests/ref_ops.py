@@ -46,9 +46,12 @@ class RefOps:
         out.copy_(y)
         return out
 
-    def gemm_norm(self, A, W, norm_w, eps, out, out_norm, bias=None, residual=None, act=0):
+    def gemm_norm(self, A, W, norm_w, eps, out, out_norm, bias=None, residual=None, act=0, norm_b=None):
         self.gemm(A, W, bias=bias, residual=residual, out=out, act=act)
-        self.rmsnorm(out, norm_w, eps, out=out_norm)
+        if norm_b is None:
+            self.rmsnorm(out, norm_w, eps, out=out_norm)
+        else:
+            self.layernorm(out, norm_w, norm_b, eps, out=out_norm)
         return out, out_norm
 
     def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=0):

@@ -134,6 +134,22 @@ def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
         ops.gemm(A.cuda(), W.cuda(), residual=rnd((M, I), 4).cuda(), act=4)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 1280, 5120), (1024, 1280, 1280), (70, 160, 320)])
+def test_gemm_layernorm_fused_reduce(ops, ref, M, N, K):
+    """svlm_gemm_bf16_norm with a norm bias = LayerNorm (the ViT's proj -> norm2 and fc2 -> next norm1), fused into the split-K
+    reduce for fc2's plan, a second launch for the others."""
+    A, W, b, r_ = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3, 0.1), rnd((M, N), 4)
+    g, gb = rnd((N,), 5, 0.1) + 1, rnd((N,), 6, 0.1)
+    x_c, xn_c = r_.clone(), torch.empty((M, N), dtype=BF16)
+    ref.gemm_norm(A, W, g, 1e-6, x_c, xn_c, bias=b, residual=x_c, norm_b=gb)
+    x_g, xn_g = r_.clone().cuda(), torch.empty((M, N), dtype=BF16, device="cuda")
+    ops.gemm_norm(A.cuda(), W.cuda(), g.cuda(), 1e-6, x_g, xn_g, bias=b.cuda(), residual=x_g, norm_b=gb.cuda())
+    close("gemm+LN out", x_g, x_c)
+    want = ops.layernorm(x_g, g.cuda(), gb.cuda(), 1e-6, out=torch.empty_like(x_g))
+    d = (xn_g.float() - want.float()).abs()
+    assert float(d.max()) <= 2 ** -6 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
+
+
 def test_gemm_inplace_residual(ops, ref):
     A, W, x = rnd((300, 256), 1), rnd((512, 256), 2, 0.05), rnd((300, 512), 3)
     want = ref.gemm(A, W, None, x)
