@@ -31,8 +31,8 @@
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 #define FA_THREADS 256
 
-template <int D, int DP>
-__global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
+template <int D, int DP, int NG>
+__global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
     const bf16_t* __restrict__ q, long q_row_stride, long q_head_stride, long q_seq_stride,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long kv_row_stride, long kv_head_stride, long kv_seq_stride,
     bf16_t* __restrict__ out, long o_row_stride, long o_head_stride, long o_seq_stride,
@@ -42,13 +42,18 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   constexpr int CPR = D / 8;           // 16-B chunks per row
   constexpr int NKS = DP / 32;         // k-steps of the QK^T product
   constexpr int NDT = D / 16;          // d tiles of the PV product
-  constexpr int NCH = (FA_KT * CPR + FA_THREADS - 1) / FA_THREADS;   // chunks staged per thread per tile
-  constexpr int KS_STAGE = FA_KT * KLD, VT_STAGE = FA_KT * FA_VLD;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[2 * KS_STAGE];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[2 * VT_STAGE];
+  // NG wave groups of 4 waves: every group serves the SAME 64 queries and takes one 32-key sub-tile of each staged
+  // "super tile" of ST = 32 * NG keys, so that two waves share a SIMD and hide each other's LDS / exp latency (the ViT's 256
+  // workgroups are one per CU).  The groups' (m, l, O) are merged through LDS at the end.
+  constexpr int THREADS = 256 * NG, ST = FA_KT * NG;
+  constexpr int NCH = (ST * CPR + THREADS - 1) / THREADS;   // chunks staged per thread per super tile
+  constexpr int KS_STAGE = ST * KLD, VT_STAGE = ST * FA_VLD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(fa_smem);
+  bf16_t* Vt = Ks + 2 * KS_STAGE;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
   const int fr = lane & 15, fq = lane >> 4;
   // n_split > 1 (prefill only, one sequence): blockIdx.z is the key split; each split covers an even number of this
   // workgroup's key tiles and leaves un-normalised (O, m, l) partials for flash_combine_kernel
@@ -63,8 +68,8 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
 
   // zero the K pad columns of both stages once (D < DP, ViT d = 80 -> 96)
   if constexpr (DP > D) {
-    for (int i = tid; i < 2 * FA_KT * (DP - D); i += FA_THREADS) {
-      const int st = i / (FA_KT * (DP - D)), r = i % (FA_KT * (DP - D));
+    for (int i = tid; i < 2 * ST * (DP - D); i += THREADS) {
+      const int st = i / (ST * (DP - D)), r = i % (ST * (DP - D));
       Ks[st * KS_STAGE + (r / (DP - D)) * KLD + D + r % (DP - D)] = 0;
     }
   }
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   // keys needed by this workgroup
   int kmax = L;
   if (causal) kmax = min(L, min(blockIdx.x * 64 + 63, T - 1) + causal_offset + 1);
-  const int n_kt_all = (kmax + FA_KT - 1) / FA_KT;
+  const int n_kt_all = (kmax + ST - 1) / ST;          // in super tiles
   const int per = ((n_kt_all + n_split - 1) / n_split + 1) & ~1;      // even: the stage parity below starts at 0
   const int kt_lo = sp * per;
   const int n_kt = min(n_kt_all, kt_lo + per);
@@ -103,12 +108,12 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   auto load_tile = [&](int kt, u32x4_t (&kreg)[NCH], u32x4_t (&vreg)[NCH]) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int idx = tid + i * FA_THREADS;
+      const int idx = tid + i * THREADS;
       const int row = idx / CPR, c = idx % CPR;
       // unconditional loads from clamped addresses + select (predicated loads become branches and make hipcc drain the
       // register ring with vmcnt(0))
-      const int j = kt * FA_KT + (idx < FA_KT * CPR ? row : 0);
-      const size_t off = (size_t)min(j, L - 1) * kv_row_stride + (idx < FA_KT * CPR ? c : 0) * 8;
+      const int j = kt * ST + (idx < ST * CPR ? row : 0);
+      const size_t off = (size_t)min(j, L - 1) * kv_row_stride + (idx < ST * CPR ? c : 0) * 8;
       kreg[i] = *reinterpret_cast<const u32x4_t*>(k + off);       // rows >= L are zeroed when the tile is stored
       vreg[i] = *reinterpret_cast<const u32x4_t*>(v + off);
     }
@@ -119,10 +124,10 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     const u32x4_t z = u32x4_t{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int idx = tid + i * FA_THREADS;
-      if (idx < FA_KT * CPR) {
+      const int idx = tid + i * THREADS;
+      if (idx < ST * CPR) {
         const int row = idx / CPR, c = idx % CPR;
-        const bool ok = kt * FA_KT + row < L;         // only the tile that crosses L zeroes anything
+        const bool ok = kt * ST + row < L;            // only the tile that crosses L zeroes anything
         *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = ok ? kreg[i] : z;
         *reinterpret_cast<u32x4_t*>(vt_ + row * FA_VLD + c * 8) = ok ? vreg[i] : z;      // V stays row-major: transposed on read
       }
@@ -130,8 +135,9 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
   };
 
   auto compute = [&](int kt, int st) {
-    const bf16_t* ks_ = Ks + st * KS_STAGE;
-    const bf16_t* vt_ = Vt + st * VT_STAGE;
+    const bf16_t* ks_ = Ks + st * KS_STAGE + grp * (FA_KT * KLD);        // this wave group's 32 keys of the super tile
+    const bf16_t* vt_ = Vt + st * VT_STAGE + grp * (FA_KT * FA_VLD);
+    const int j0 = kt * ST + grp * FA_KT;
     // ---- S^T = K . Q^T   (two 16-key sub-tiles)
     f32x4_t sacc[2];
 #pragma unroll
@@ -151,14 +157,14 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sv[sub * 4 + r] = sacc[sub][r];
-    const int j_hi = kt * FA_KT + FA_KT - 1;
+    const int j_hi = j0 + FA_KT - 1;
     const bool need_mask = j_hi >= L || (causal && j_hi > qbase + causal_offset);      // qbase = smallest query of the wave
     unsigned okbits = 0xFFu;
     if (need_mask) {
       okbits = 0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = kt * FA_KT + (i >> 2) * 16 + fq * 4 + (i & 3);
+        const int j = j0 + (i >> 2) * 16 + fq * 4 + (i & 3);
         const bool ok = j < L && (!causal || j <= tq + causal_offset);
         sv[i] = ok ? sv[i] : -1e30f;
         okbits |= ok ? (1u << i) : 0u;
@@ -229,6 +235,39 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
     lds_barrier();
   }
 
+  // ---- merge of the wave groups: group g > 0 leaves (m, l, O) in the (now idle) staging LDS, group 0 folds them in
+  if constexpr (NG > 1) {
+    float* mg = reinterpret_cast<float*>(fa_smem);
+    constexpr int MW = NDT * 4 + 2;                    // floats per thread, stored thread-minor (conflict-free)
+    const int t256 = tid & 255;
+#pragma unroll
+    for (int g = 1; g < NG; ++g) {
+      if (grp == g) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mg[(dt * 4 + r) * 256 + t256] = oacc[dt][r];
+        mg[(NDT * 4) * 256 + t256] = m_run;
+        mg[(NDT * 4 + 1) * 256 + t256] = l_run;
+      }
+      __syncthreads();
+      if (grp == 0) {
+        const float m1 = mg[(NDT * 4) * 256 + t256], l1 = mg[(NDT * 4 + 1) * 256 + t256];
+        const float M = fmaxf(m_run, m1);
+        const float a0 = exp2f((m_run - M) * cexp), a1 = exp2f((m1 - M) * cexp);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[dt][r] = oacc[dt][r] * a0 + mg[(dt * 4 + r) * 256 + t256] * a1;
+        l_run = l_run * a0 + l1 * a1;
+        m_run = M;
+      }
+      if (g + 1 < NG) __syncthreads();
+    }
+    static_assert(MW * 256 * 4 <= 2 * (KS_STAGE + VT_STAGE) * 2, "merge buffer must fit the staging LDS");
+    if (grp != 0) return;
+  }
+
   // ---- epilogue: lane holds O[tq][dt*16 + 4*fq + r]
   if (n_split > 1) {
     if (tq < T) {
@@ -254,6 +293,26 @@ __global__ __launch_bounds__(FA_THREADS) void flash_attn_kernel(
       *reinterpret_cast<u32x2_t*>(orow + dt * 16 + fq * 4) = o;
     }
   }
+}
+
+template <int D, int DP, int NG>
+static int fa_smem_bytes() {
+  return 2 * (FA_KT * NG * (DP + 8) + FA_KT * NG * FA_VLD) * 2;
+}
+// Sets the dynamic-LDS limit once per instantiation (> 64 KB for two wave groups at d = 128).
+template <int D, int DP, int NG>
+static void fa_prepare() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D, DP, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        fa_smem_bytes<D, DP, NG>());
+    done = true;
+  }
+}
+static int fa_groups(const char* env, int dflt) {
+  const char* e = getenv(env);
+  const int v = e ? atoi(e) : dflt;
+  return v == 2 ? 2 : 1;
 }
 
 // Merge of the key splits: out[t][h][:] = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max_s m_s) * scale*log2 e).
@@ -411,8 +470,18 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   float* part_o = (float*)(v_lin + (size_t)Hkv * L * 128);
   float* part_ml = part_o + (size_t)ns * T * Hq * 128;
   dim3 grid((T + 63) / 64, Hq, ns);
-  flash_attn_kernel<128, 128><<<grid, FA_THREADS, 0, st>>>(q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out,
-                                                           o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv, scale, ns, part_o, part_ml);
+  static const int ng = fa_groups("SVLM_PREFILL_FA_GROUPS", 1);
+  if (ng == 2) {
+    fa_prepare<128, 128, 2>();
+    flash_attn_kernel<128, 128, 2><<<grid, 512, fa_smem_bytes<128, 128, 2>(), st>>>(
+        q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out, o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv,
+        scale, ns, part_o, part_ml);
+  } else {
+    fa_prepare<128, 128, 1>();
+    flash_attn_kernel<128, 128, 1><<<grid, 256, fa_smem_bytes<128, 128, 1>(), st>>>(
+        q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out, o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv,
+        scale, ns, part_o, part_ml);
+  }
   rc = svlm_check_launch("svlm_prefill_attn_ropeload");
   if (rc || ns == 1) return rc;
   const long n_thr = (long)T * Hq * 32;
@@ -428,14 +497,22 @@ extern "C" int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len,
   const bf16_t* base = (const bf16_t*)qkv;
   const long row = 3L * H * d;
   dim3 grid((seq_len + 63) / 64, H, n_seq);
+  // two wave groups per workgroup (2 waves per SIMD share every staged K/V tile): 33 -> 24 us for the 1024-token frame; the
+  // 64-token Qwen2.5 windows hold a single 64-key super tile and keep one group
+  static const int ng_env = fa_groups("SVLM_VIT_FA_GROUPS", 0);
+  const int ng = getenv("SVLM_VIT_FA_GROUPS") ? ng_env : (seq_len >= 256 ? 2 : 1);
+#define SVLM_VIT_FA(D_, DP_, NG_)                                                                                           \
+  do {                                                                                                                      \
+    fa_prepare<D_, DP_, NG_>();                                                                                             \
+    flash_attn_kernel<D_, DP_, NG_><<<grid, 256 * NG_, fa_smem_bytes<D_, DP_, NG_>(), (hipStream_t)stream>>>(               \
+        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,            \
+        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale, 1, nullptr, nullptr);                   \
+  } while (0)
   if (d == 80) {
-    flash_attn_kernel<80, 96><<<grid, FA_THREADS, 0, (hipStream_t)stream>>>(
-        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,
-        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale, 1, nullptr, nullptr);
+    if (ng == 2) SVLM_VIT_FA(80, 96, 2); else SVLM_VIT_FA(80, 96, 1);
   } else {
-    flash_attn_kernel<128, 128><<<grid, FA_THREADS, 0, (hipStream_t)stream>>>(
-        base, row, d, row * seq_len, base + (long)H * d, base + 2L * H * d, row, d, row * seq_len, (bf16_t*)out,
-        (long)H * d, d, (long)H * d * seq_len, seq_len, seq_len, 0, 0, H, H, scale, 1, nullptr, nullptr);
+    if (ng == 2) SVLM_VIT_FA(128, 128, 2); else SVLM_VIT_FA(128, 128, 1);
   }
+#undef SVLM_VIT_FA
   return svlm_check_launch("svlm_vit_attn");
 }
