@@ -89,6 +89,18 @@ int svlm_gather_rows(const void* table, const void* alt, const int* idx, const i
  * $TF/models/qwen2_vl/video_processing_qwen2_vl.py:247-270) -- SURVEY 8f-2. */
 int svlm_patchify_u8(const void* frames, void* out, int T, int H, int W, int patch, int temporal, int merge,
                      float m0, float m1, float m2, float s0, float s1, float s2, void* stream);
+/* Frame ingest, resize: uint8 planes (planes = T*C, H, W) -> uint8 (planes, h, w) by the separable antialiased bicubic filter
+ * of torch's interpolate(mode="bicubic", antialias=True, align_corners=False) in fp32 -- width pass, height pass, clamp to
+ * [0, 255], round half to even.  svlm_resize_aa_tables is HOST arithmetic (callable without a GPU): the tap tables of one axis
+ * (first tap, tap count, normalised weights with row stride wt_stride >= K); it returns K and, with NULL pointers, only sizes
+ * the buffers.  The caller uploads the two axes' tables; ws >= svlm_resize_ws_bytes(planes, H, w) holds the fp32 width pass.
+ * replaces: _spatial_resize_video = torchvision resize(BICUBIC, antialias=True) on the decoded clip
+ * (livecc_utils/src/livecc_utils/video_process_patch.py:134-153) -- SURVEY 8f-2. */
+int svlm_resize_aa_tables(int in_size, int out_size, int* xmin, int* xsize, float* wt, int wt_stride);
+long long svlm_resize_ws_bytes(int planes, int H, int w);
+int svlm_resize_bicubic_aa_u8(const void* src, void* dst, int planes, int H, int W, int h, int w, const int* xmin, const int* xsize,
+                              const float* wt_x, int Kx, const int* ymin, const int* ysize, const float* wt_y, int Ky, void* ws,
+                              long long ws_bytes, void* stream);
 
 /* In-place 2-D rope on the q and k parts of the fused ViT qkv buffer (N,3,H,d); cosT/sinT fp32 (N,d/2).
  * replaces: apply_rotary_pos_emb_vision (qwen2/vision_forward.py:27). */

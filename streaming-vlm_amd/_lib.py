@@ -36,6 +36,9 @@ SIGNATURES = {
     "svlm_silu_mul": (_i, [_p, _p, _i, _i, _p]),
     "svlm_gather_rows": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     "svlm_patchify_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _p]),
+    "svlm_resize_aa_tables": (_i, [_i, _i, _p, _p, _p, _i]),
+    "svlm_resize_ws_bytes": (_ll, [_i, _i, _i]),
+    "svlm_resize_bicubic_aa_u8": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _i, _p, _ll, _p]),
     "svlm_vit_rope": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "svlm_vit_attn": (_i, [_p, _p, _i, _i, _i, _i, _f, _p]),
     "svlm_mrope_table": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -1,0 +1,129 @@
+// Frame ingest, first half: antialiased bicubic resize of uint8 frames.
+//
+// The reference resizes every decoded clip on the host before the processor sees it
+// (livecc_utils/src/livecc_utils/video_process_patch.py:134-153: torchvision's tensor resize, BICUBIC, antialias=True, on the
+// uint8 (T, C, H, W) clip).  torchvision's tensor path is torch's separable antialias filter in fp32 followed by clamp, round
+// half to even and the cast back to uint8; the tap tables below restate the helper formulas torch publishes in
+// ATen/native/(hip|cuda)/UpSample.cuh (namespace upsample_antialias).  Width pass first (uint8 -> fp32), height pass second
+// (fp32 -> uint8).  Both passes are plain HBM streams: one thread per output value, taps read through L1/L2, fp32 products
+// and sums in tap order WITHOUT fused multiply-add (the oracle's, i.e. an unfused CPU's, operation order).
+#include "common.h"
+
+#include <math.h>
+
+static float resize_cubic(float x) {
+  const float a = -0.5f;
+  x = fabsf(x);
+  if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+  return 0.f;
+}
+
+// Host arithmetic only (no GPU): tap tables of ONE axis.  Returns K, the row stride of `wt` (taps per output, incl. zero
+// padding), after filling xmin[out_size], xsize[out_size] and wt[out_size * K] when they are non-NULL (call once with NULL
+// pointers to size the buffers); negative on bad arguments.  Every operation is fp32, in the oracle's order.
+extern "C" int svlm_resize_aa_tables(int in_size, int out_size, int* xmin, int* xsize, float* wt, int wt_stride) {
+  if (in_size <= 0 || out_size <= 0) return SVLM_EINVAL;
+  const volatile float scale = (float)in_size / (float)out_size;
+  const volatile float support = scale >= 1.f ? 2.0f * scale : 2.0f;
+  const volatile float invscale = scale >= 1.f ? 1.0f / scale : 1.0f;
+  const int K = (int)ceilf(support) * 2 + 1;
+  if (!xmin && !xsize && !wt) return K;
+  if (!xmin || !xsize || !wt || wt_stride < K) return SVLM_EINVAL;
+  for (int i = 0; i < out_size; ++i) {
+    const volatile float center = scale * ((float)i + 0.5f);
+    volatile float t = center - support;
+    t = t + 0.5f;
+    int lo = (int)t;
+    lo = lo > 0 ? lo : 0;
+    t = center + support;
+    t = t + 0.5f;
+    int hi = (int)t;
+    hi = hi < in_size ? hi : in_size;
+    int n = hi - lo;
+    n = n < 0 ? 0 : (n > K ? K : n);
+    volatile float tot = 0.f;
+    float* w = wt + (size_t)i * wt_stride;
+    for (int j = 0; j < n; ++j) {
+      volatile float x = (float)(j + lo) - center;
+      x = x + 0.5f;
+      x = x * invscale;
+      w[j] = resize_cubic(x);
+      tot = tot + w[j];
+    }
+    for (int j = 0; j < n; ++j)
+      if (tot != 0.f) w[j] = w[j] / tot;
+    for (int j = n; j < wt_stride; ++j) w[j] = 0.f;
+    xmin[i] = lo;
+    xsize[i] = n;
+  }
+  return K;
+}
+
+// width pass: src uint8 (planes, H, W) -> tmp fp32 (planes, H, w)
+__global__ __launch_bounds__(256) void resize_aa_width_kernel(const unsigned char* __restrict__ src, float* __restrict__ tmp,
+                                                              const int* __restrict__ xmin, const int* __restrict__ xsize,
+                                                              const float* __restrict__ wt, int K, long long rows, int W, int w) {
+#pragma clang fp contract(off)      // the HIP __fmul_rn / __fadd_rn are plain operators: without this hipcc fuses them
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= rows * w) return;
+  const int xo = (int)(i % w);
+  const long long row = i / w;
+  const unsigned char* s = src + row * W + xmin[xo];
+  const float* wr = wt + (size_t)xo * K;
+  const int n = xsize[xo];
+  float acc = (float)s[0] * wr[0];
+  for (int j = 1; j < n; ++j) {
+    const float p = (float)s[j] * wr[j];
+    acc = acc + p;
+  }
+  tmp[i] = n > 0 ? acc : 0.f;
+}
+
+// height pass: tmp fp32 (planes, H, w) -> dst uint8 (planes, h, w), clamp + round half to even
+__global__ __launch_bounds__(256) void resize_aa_height_kernel(const float* __restrict__ tmp, unsigned char* __restrict__ dst,
+                                                               const int* __restrict__ ymin, const int* __restrict__ ysize,
+                                                               const float* __restrict__ wt, int K, long long planes, int H, int h,
+                                                               int w) {
+#pragma clang fp contract(off)
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= planes * h * w) return;
+  const int xo = (int)(i % w);
+  const int yo = (int)((i / w) % h);
+  const long long p = i / ((long long)w * h);
+  const float* s = tmp + (p * H + ymin[yo]) * w + xo;
+  const float* wr = wt + (size_t)yo * K;
+  const int n = ysize[yo];
+  float acc = s[0] * wr[0];
+  for (int j = 1; j < n; ++j) {
+    const float p = s[(size_t)j * w] * wr[j];
+    acc = acc + p;
+  }
+  acc = n > 0 ? acc : 0.f;
+  acc = fminf(fmaxf(acc, 0.f), 255.f);
+  dst[i] = (unsigned char)rintf(acc);
+}
+
+extern "C" long long svlm_resize_ws_bytes(int planes, int H, int w) {
+  if (planes <= 0 || H <= 0 || w <= 0) return SVLM_EINVAL;
+  return (long long)planes * H * w * (long long)sizeof(float);
+}
+
+extern "C" int svlm_resize_bicubic_aa_u8(const void* src, void* dst, int planes, int H, int W, int h, int w, const int* xmin,
+                                         const int* xsize, const float* wt_x, int Kx, const int* ymin, const int* ysize,
+                                         const float* wt_y, int Ky, void* ws, long long ws_bytes, void* stream) {
+  SVLM_CHECK_ARG(planes > 0 && H > 0 && W > 0 && h > 0 && w > 0, "svlm_resize_bicubic_aa_u8: bad shape planes=%d %dx%d -> %dx%d", planes, H,
+                 W, h, w);
+  SVLM_CHECK_ARG(Kx > 0 && Ky > 0 && xmin && xsize && wt_x && ymin && ysize && wt_y, "svlm_resize_bicubic_aa_u8: missing tap tables (Kx=%d Ky=%d)", Kx, Ky);
+  SVLM_CHECK_ARG(ws && ws_bytes >= svlm_resize_ws_bytes(planes, H, w), "svlm_resize_bicubic_aa_u8: workspace %lld < %lld bytes", ws_bytes,
+                 svlm_resize_ws_bytes(planes, H, w));
+  hipStream_t st = (hipStream_t)stream;
+  const long long rows = (long long)planes * H;
+  const long long n1 = rows * w, n2 = (long long)planes * h * w;
+  SVLM_CHECK_ARG(n1 < (1LL << 39) && n2 < (1LL << 39), "svlm_resize_bicubic_aa_u8: clip too large (%lld values)", n1 > n2 ? n1 : n2);
+  resize_aa_width_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>((const unsigned char*)src, (float*)ws, xmin, xsize, wt_x, Kx, rows, W, w);
+  int rc = svlm_check_launch("svlm_resize_bicubic_aa_u8(width)");
+  if (rc) return rc;
+  resize_aa_height_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>((const float*)ws, (unsigned char*)dst, ymin, ysize, wt_y, Ky, planes, H, h, w);
+  return svlm_check_launch("svlm_resize_bicubic_aa_u8(height)");
+}

@@ -191,6 +191,17 @@ def printq(*args, quiet=False, **kwargs):
 
 
 # ----------------------------------------------------------------------------- main loop
+def _fetch_chunk(video, start_s, duration_s, model, device):
+    """Frames of one chunk; a source of native-size frames (`spatial_resize = True`) goes through the reference's
+    _spatial_resize_video (inference.py:342), resized on the device by svlm_resize_bicubic_aa_u8."""
+    frames = video.chunk(start_s, duration_s)
+    if getattr(video, "spatial_resize", False) and torch.is_tensor(frames):
+        from .ingest import spatial_resize_video
+        eng = getattr(model, "_svlm_engine", None)
+        frames = spatial_resize_video(frames, getattr(eng, "ops", None), device)
+    return frames
+
+
 def streaming_inference(model_path="", video_path="", output_dir=None, model_base="Qwen2_5", model=None, processor=None,
                         window_size=DEFAULT_WINDOW_SIZE, chunk_duration=DEFAULT_CHUNK_DURATION, text_round=DEFAULT_TEXT_ROUND,
                         previous_text="", test_data_json=None, test_data_idx=None, pos_mode="shrink", all_text=False,
@@ -292,7 +303,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         _sync(); _t = time.perf_counter()
         ahead, lookahead = lookahead, None
         try:
-            current_video_chunk = ahead[0] if ahead is not None else video.chunk(start_time, chunk_duration)
+            current_video_chunk = ahead[0] if ahead is not None else _fetch_chunk(video, start_time, chunk_duration, model, device)
         except Exception as e:                          # the reference breaks the loop on a decode failure (:343-345)
             print(f"Error in streaming_inference: {e}")
             break
@@ -331,7 +342,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
             # frames do not depend on the generated text: fetch the next chunk's now so its ViT pass can run underneath
             # this chunk's decode steps (engine.vision_prefetch)
             try:
-                nf = video.chunk(start_time + chunk_duration, chunk_duration)
+                nf = _fetch_chunk(video, start_time + chunk_duration, chunk_duration, model, device)
                 nin = processor(text=["<|vision_start|><|video_pad|><|vision_end|>"], videos=nf, padding=True, return_tensors="pt")
                 lookahead = (nf, nin["pixel_values_videos"].to(device), nin["video_grid_thw"])
             except Exception:

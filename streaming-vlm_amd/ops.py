@@ -40,6 +40,22 @@ def _req(t, dtype, name, dims=None):
         raise _lib.SvlmError(f"{name}: innermost dimension must be contiguous")
 
 
+def aa_resize_tables(in_size, out_size):
+    """Tap tables (first tap, tap count, weights) of one axis of the antialiased bicubic resize, from the library's HOST
+    function svlm_resize_aa_tables (no GPU involved)."""
+    import numpy as np
+    lib = _lib.load()
+    K = lib.svlm_resize_aa_tables(in_size, out_size, None, None, None, 0)
+    if K <= 0:
+        raise _lib.SvlmError(f"svlm_resize_aa_tables({in_size}, {out_size}): bad arguments")
+    xmin, xsize = np.zeros(out_size, np.int32), np.zeros(out_size, np.int32)
+    wt = np.zeros((out_size, K), np.float32)
+    rc = lib.svlm_resize_aa_tables(in_size, out_size, xmin.ctypes.data, xsize.ctypes.data, wt.ctypes.data, K)
+    if rc != K:
+        raise _lib.SvlmError(f"svlm_resize_aa_tables({in_size}, {out_size}) -> {rc}")
+    return xmin, xsize, wt
+
+
 class HipOps:
     """The only ops backend the product ships."""
 
@@ -50,6 +66,7 @@ class HipOps:
         if not torch.cuda.is_available():
             raise _lib.SvlmError("no HIP device visible: the svlm hot path only runs on an MI355X (gfx950) GPU")
         self._gemm_ws = {}          # per-device fp32 scratch for split-K slabs
+        self._resize_tabs = {}      # (device, H, W, h, w) -> device tap tables of the frame resize
 
     GEMM_WS_BYTES = 96 << 20
 
@@ -204,6 +221,37 @@ class HipOps:
         check(self.lib.svlm_patchify_u8(_ptr(frames), _ptr(out), T, H, W, patch, temporal, merge, f32(mean[0]), f32(mean[1]), f32(mean[2]),
                                         f32(std[0]), f32(std[1]), f32(std[2]), _stream()), "svlm_patchify_u8")
         return out, [[gt, gh, gw]]
+
+    def resize_tables(self, in_size, out_size):
+        return aa_resize_tables(in_size, out_size)
+
+    def resize_u8(self, frames, h, w, out=None):
+        """uint8 (T, C, H, W) frames on the device -> uint8 (T, C, h, w): torchvision's resize(BICUBIC, antialias=True)."""
+        _req(frames, torch.uint8, "resize.frames", 4)
+        T, Cc, H, W = frames.shape
+        assert frames.is_contiguous()
+        if out is None:
+            out = torch.empty((T, Cc, h, w), dtype=torch.uint8, device=frames.device)
+        _req(out, torch.uint8, "resize.out", 4)
+        assert out.is_contiguous() and tuple(out.shape) == (T, Cc, h, w)
+        key = (str(frames.device), H, W, h, w)
+        tabs = self._resize_tabs.get(key)
+        if tabs is None:
+            tx, ty = self.resize_tables(W, w), self.resize_tables(H, h)
+            tabs = tuple(torch.from_numpy(a).to(frames.device) for a in tx + ty)
+            if len(self._resize_tabs) > 16:
+                self._resize_tabs.clear()
+            self._resize_tabs[key] = tabs
+        xmin, xsize, wx, ymin, ysize, wy = tabs
+        need = self.lib.svlm_resize_ws_bytes(T * Cc, H, w)
+        ws = self._gemm_ws.get("rz" + str(frames.device))
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.empty(max(need // 4, 1 << 18), dtype=torch.float32, device=frames.device)
+            self._gemm_ws["rz" + str(frames.device)] = ws
+        check(self.lib.svlm_resize_bicubic_aa_u8(_ptr(frames), _ptr(out), T * Cc, H, W, h, w, _ptr(xmin), _ptr(xsize), _ptr(wx),
+                                                 wx.shape[1], _ptr(ymin), _ptr(ysize), _ptr(wy), wy.shape[1], _ptr(ws),
+                                                 ws.numel() * 4, _stream()), "svlm_resize_bicubic_aa_u8")
+        return out
 
     # ------------------------------------------------------------------ ViT
     def vit_rope(self, qkv, cosT, sinT, H, d):

@@ -38,8 +38,13 @@ def synthetic_frame(stream: int, t: int, size=448) -> torch.Tensor:
 class SyntheticVideo:
     """Stand-in for the decord reader: frames are addressed by index at `fps` frames per second."""
 
-    def __init__(self, size=448, fps: float = 1.0, stream: int = 0):
+    # True = "decoded at the file's native size": the driver then applies the reference's per-chunk _spatial_resize_video
+    # (inference.py:342) through the HIP resize; False = frames already at processor size (every BASELINE stream)
+    spatial_resize = False
+
+    def __init__(self, size=448, fps: float = 1.0, stream: int = 0, spatial_resize: bool = False):
         self.size, self.fps, self.stream = size, fps, stream
+        self.spatial_resize = spatial_resize
 
     def chunk(self, start_s: float, duration_s: float) -> torch.Tensor:
         n = max(1, int(round(duration_s * self.fps)))
@@ -48,12 +53,13 @@ class SyntheticVideo:
 
     @classmethod
     def from_path(cls, path: str) -> Optional["SyntheticVideo"]:
-        """``synthetic://448x448@1fps?stream=3``"""
-        m = re.fullmatch(r"synthetic://(\d+)x(\d+)@([\d.]+)fps(?:\?stream=(\d+))?", path or "")
+        """``synthetic://448x448@1fps?stream=3``; ``synthetic-raw://1280x720@2fps`` = native-size frames that still need the
+        reference's smart resize."""
+        m = re.fullmatch(r"synthetic(-raw)?://(\d+)x(\d+)@([\d.]+)fps(?:\?stream=(\d+))?", path or "")
         if not m:
             return None
-        w, h = int(m.group(1)), int(m.group(2))          # WxH, like a resolution string
-        return cls(w if w == h else (h, w), float(m.group(3)), int(m.group(4) or 0))
+        w, h = int(m.group(2)), int(m.group(3))          # WxH, like a resolution string
+        return cls(w if w == h else (h, w), float(m.group(4)), int(m.group(5) or 0), spatial_resize=bool(m.group(1)))
 
 
 def patchify(frames: torch.Tensor, patch: int = 14, temporal: int = 2, merge: int = 2, device=None):
@@ -233,7 +239,7 @@ class DeviceFrameProcessor(SyntheticProcessor):
     def __call__(self, text=None, videos=None, padding=True, return_tensors="pt", **kw):
         if videos is None:
             return super().__call__(text=text, videos=None, padding=padding, return_tensors=return_tensors, **kw)
-        frames = videos.to(self.device, non_blocking=True)
+        frames = videos.to(self.device, non_blocking=True)          # (a clip the driver resized is on the device already)
         pix, grid = self.ops.patchify_u8(frames.contiguous(), self.patch, self.temporal, self.merge)
         t = (text if isinstance(text, str) else text[0])
         assert t.count("<|video_pad|>") == 1, "one video per call"

@@ -305,3 +305,42 @@ def test_tiny_stream_with_the_7b_head_grouping():
     sd = random_state_dict(cfg, 0, "cpu")
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8)
     _compare(cfg, sd, 5, model)
+
+
+def test_native_size_frames_are_resized_on_the_device():
+    """A source of native-size frames (`synthetic-raw://`) goes through the reference's per-chunk _spatial_resize_video
+    (inference.py:342) on the GPU: the stream equals, bit for bit, the stream over the ORACLE-resized frames."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import ingest
+    from oracle import resize as R
+
+    class Presized:
+        spatial_resize = False
+
+        def __init__(self, raw):
+            self.raw = raw
+
+        def chunk(self, start_s, duration_s):
+            f = self.raw.chunk(start_s, duration_s)
+            h, w = ingest.resized_shape(f.shape[2], f.shape[3], f.shape[0])
+            return torch.from_numpy(R.resize_bicubic_aa_u8(f.numpy(), h, w))
+
+    path = "synthetic-raw://330x250@1fps"
+    assert ingest.resized_shape(250, 330, 1) == (252, 336)
+    outs = []
+    for presized in (False, True):
+        cfg, sd, model = _tiny_model()
+        proc = S.DeviceFrameProcessor(model._svlm_engine.ops)
+        raw = S.SyntheticVideo.from_path(path)
+        ids_log = []
+        S.streaming_inference(model=model, processor=proc, video=Presized(raw) if presized else raw, video_path=path, model_base="Qwen2",
+                              duration=3, previous_text="hello world", kv_policy="sink_window", sink=4, window=160, do_sample=False,
+                              max_new_tokens=8, suppress_eos=True, quiet=True, ids_log=ids_log, keep_logits=True)
+        outs.append(ids_log)
+    assert len(outs[0]) == 3
+    for a, b in zip(*outs):
+        assert a["ids"] == b["ids"] and a["ids"].count(151656) > 0
+        for x, y in zip(a["logits"], b["logits"]):
+            assert torch.equal(x, y)
+    n_pad = outs[0][0]["ids"].count(151656)
+    assert n_pad % ((252 // 28) * (336 // 28)) == 0, n_pad           # 108 video tokens per chunk: the resized grid

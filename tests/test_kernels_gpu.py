@@ -491,3 +491,24 @@ def test_fused_decode_kernels(ops, ref, H, Hq, Hkv, I, V):
     assert torch.equal(st_g.cpu(), st_c)
     if int(tb_g[1]) != int(tb_c[1]):
         print("[fused] token differs from oracle (top-2 margin inside rounding noise)")
+
+
+# ----------------------------------------------------------------------------- frame resize
+@pytest.mark.parametrize("T,H,W,h,w", [(2, 360, 640, 252, 448), (1, 240, 320, 336, 448), (3, 100, 80, 56, 42), (2, 64, 64, 64, 64),
+                                       (1, 37, 53, 28, 28), (2, 720, 1280, 252, 448), (1, 30, 40, 56, 70), (1, 1080, 1920, 560, 1008)])
+def test_resize_bicubic_aa_u8_bit_exact(ops, T, H, W, h, w):
+    """svlm_resize_bicubic_aa_u8 == the oracle's fp32 separable antialias filter, bit for bit (down- and up-scaling, 5 to 13
+    taps per axis, identity at equal sizes); the oracle itself is pinned against torch's interpolate in tests/test_resize.py."""
+    from oracle import resize as R
+    g = torch.Generator().manual_seed(H * 3 + w + T)
+    x = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
+    if T > 1:
+        x[1] = (torch.arange(W).view(1, 1, W) * 255 // (W - 1) + torch.arange(H).view(1, H, 1)).clamp(0, 255).to(torch.uint8)
+    want = R.resize_bicubic_aa_u8(x.numpy(), h, w)
+    got = ops.resize_u8(x.cuda(), h, w)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (T, 3, h, w)
+    assert np.array_equal(got.cpu().numpy(), want)
+    again = ops.resize_u8(x.cuda(), h, w)                 # cached tables, reused scratch
+    assert torch.equal(again, got)
+    with pytest.raises(Exception):
+        ops.resize_u8(x.cuda().float(), h, w)
