@@ -60,48 +60,50 @@ extern "C" int svlm_resize_aa_tables(int in_size, int out_size, int* xmin, int* 
   return K;
 }
 
-// width pass: src uint8 (planes, H, W) -> tmp fp32 (planes, H, w)
+// width pass: src uint8 (rows = planes*H, W) -> tmp fp32 (rows, w); blockIdx.y = row (folded over 65535), blockIdx.x = 256 outputs
 __global__ __launch_bounds__(256) void resize_aa_width_kernel(const unsigned char* __restrict__ src, float* __restrict__ tmp,
                                                               const int* __restrict__ xmin, const int* __restrict__ xsize,
                                                               const float* __restrict__ wt, int K, long long rows, int W, int w) {
 #pragma clang fp contract(off)      // the HIP __fmul_rn / __fadd_rn are plain operators: without this hipcc fuses them
-  const long long i = blockIdx.x * 256LL + threadIdx.x;
-  if (i >= rows * w) return;
-  const int xo = (int)(i % w);
-  const long long row = i / w;
-  const unsigned char* s = src + row * W + xmin[xo];
-  const float* wr = wt + (size_t)xo * K;
+  const int xo = blockIdx.x * 256 + threadIdx.x;
+  if (xo >= w) return;
   const int n = xsize[xo];
-  float acc = (float)s[0] * wr[0];
-  for (int j = 1; j < n; ++j) {
-    const float p = (float)s[j] * wr[j];
-    acc = acc + p;
+  const int x0 = xmin[xo];
+  const float* wr = wt + (size_t)xo * K;
+  for (long long row = blockIdx.y; row < rows; row += gridDim.y) {
+    const unsigned char* s = src + row * W + x0;
+    float acc = (float)s[0] * wr[0];
+    for (int j = 1; j < n; ++j) {
+      const float p = (float)s[j] * wr[j];
+      acc = acc + p;
+    }
+    tmp[row * w + xo] = n > 0 ? acc : 0.f;
   }
-  tmp[i] = n > 0 ? acc : 0.f;
 }
 
-// height pass: tmp fp32 (planes, H, w) -> dst uint8 (planes, h, w), clamp + round half to even
+// height pass: tmp fp32 (planes, H, w) -> dst uint8 (planes, h, w), clamp + round half to even; blockIdx.y = plane*h + yo
 __global__ __launch_bounds__(256) void resize_aa_height_kernel(const float* __restrict__ tmp, unsigned char* __restrict__ dst,
                                                                const int* __restrict__ ymin, const int* __restrict__ ysize,
                                                                const float* __restrict__ wt, int K, long long planes, int H, int h,
                                                                int w) {
 #pragma clang fp contract(off)
-  const long long i = blockIdx.x * 256LL + threadIdx.x;
-  if (i >= planes * h * w) return;
-  const int xo = (int)(i % w);
-  const int yo = (int)((i / w) % h);
-  const long long p = i / ((long long)w * h);
-  const float* s = tmp + (p * H + ymin[yo]) * w + xo;
-  const float* wr = wt + (size_t)yo * K;
-  const int n = ysize[yo];
-  float acc = s[0] * wr[0];
-  for (int j = 1; j < n; ++j) {
-    const float p = s[(size_t)j * w] * wr[j];
-    acc = acc + p;
+  const int xo = blockIdx.x * 256 + threadIdx.x;
+  if (xo >= w) return;
+  for (long long r = blockIdx.y; r < planes * h; r += gridDim.y) {
+    const int yo = (int)(r % h);
+    const long long p = r / h;
+    const float* s = tmp + (p * H + ymin[yo]) * w + xo;
+    const float* wr = wt + (size_t)yo * K;
+    const int n = ysize[yo];
+    float acc = s[0] * wr[0];
+    for (int j = 1; j < n; ++j) {
+      const float pr = s[(size_t)j * w] * wr[j];
+      acc = acc + pr;
+    }
+    acc = n > 0 ? acc : 0.f;
+    acc = fminf(fmaxf(acc, 0.f), 255.f);
+    dst[r * w + xo] = (unsigned char)rintf(acc);
   }
-  acc = n > 0 ? acc : 0.f;
-  acc = fminf(fmaxf(acc, 0.f), 255.f);
-  dst[i] = (unsigned char)rintf(acc);
 }
 
 extern "C" long long svlm_resize_ws_bytes(int planes, int H, int w) {
@@ -121,9 +123,11 @@ extern "C" int svlm_resize_bicubic_aa_u8(const void* src, void* dst, int planes,
   const long long rows = (long long)planes * H;
   const long long n1 = rows * w, n2 = (long long)planes * h * w;
   SVLM_CHECK_ARG(n1 < (1LL << 39) && n2 < (1LL << 39), "svlm_resize_bicubic_aa_u8: clip too large (%lld values)", n1 > n2 ? n1 : n2);
-  resize_aa_width_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>((const unsigned char*)src, (float*)ws, xmin, xsize, wt_x, Kx, rows, W, w);
+  const unsigned gx = (unsigned)((w + 255) / 256);
+  resize_aa_width_kernel<<<dim3(gx, (unsigned)(rows < 65535 ? rows : 65535)), 256, 0, st>>>((const unsigned char*)src, (float*)ws, xmin, xsize, wt_x, Kx, rows, W, w);
   int rc = svlm_check_launch("svlm_resize_bicubic_aa_u8(width)");
   if (rc) return rc;
-  resize_aa_height_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>((const float*)ws, (unsigned char*)dst, ymin, ysize, wt_y, Ky, planes, H, h, w);
+  const long long r2 = (long long)planes * h;
+  resize_aa_height_kernel<<<dim3(gx, (unsigned)(r2 < 65535 ? r2 : 65535)), 256, 0, st>>>((const float*)ws, (unsigned char*)dst, ymin, ysize, wt_y, Ky, planes, H, h, w);
   return svlm_check_launch("svlm_resize_bicubic_aa_u8(height)");
 }

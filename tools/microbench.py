@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Launch one kernel of the path repeatedly on BASELINE shapes (for rocprofv3 --pmc / --kernel-trace runs).
-    python tools/microbench.py vit_attn|prefill_attn|gemm_fc2|gemm_qkv|decode_attn|gemv_down [reps]"""
+    python tools/microbench.py vit_attn|prefill_attn|gemm_fc2|gemm_qkv|decode_attn|gemv_down|resize [reps]"""
 import math
 import os
 import sys
@@ -45,6 +45,11 @@ elif which == "dec_gate_up":
     Ws = [r(2 * I, H) for _ in range(28)]
     x, lnw, h = r(H), r(H), torch.empty(I, dtype=bf, device=dev)
     fn = lambda: [o.dec_gate_up(x, lnw, 1e-6, W, h) for W in Ws]
+elif which == "resize":
+    # one chunk of a 720p source at 2 fps: (2, 3, 720, 1280) uint8 -> (2, 3, 560, 1008), the reference's smart-resized size
+    src = torch.randint(0, 256, (2, 3, 720, 1280), dtype=torch.uint8, device=dev)
+    dst = torch.empty((2, 3, 560, 1008), dtype=torch.uint8, device=dev)
+    fn = lambda: o.resize_u8(src, 560, 1008, out=dst)
 elif which == "gemv_down":
     x, W, y = r(8960), r(1536, 8960), torch.zeros(1536, dtype=bf, device=dev)
     fn = lambda: o.gemv(x, W, residual=y, out=y)
