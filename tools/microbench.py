@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Launch one kernel of the path repeatedly on BASELINE shapes (for rocprofv3 --pmc / --kernel-trace runs).
-    python tools/microbench.py vit_attn|prefill_attn|gemm_fc2|gemm_qkv|decode_attn|gemv_down|resize [reps]"""
+    python tools/microbench.py vit_attn|prefill_attn|gemm_fc2|gemm_qkv|decode_attn|gemv_down|resize|gu_cold|gu_prefetched|pf_only [reps]"""
 import math
 import os
 import sys
@@ -45,6 +45,24 @@ elif which == "dec_gate_up":
     Ws = [r(2 * I, H) for _ in range(28)]
     x, lnw, h = r(H), r(H), torch.empty(I, dtype=bf, device=dev)
     fn = lambda: [o.dec_gate_up(x, lnw, 1e-6, W, h) for W in Ws]
+elif which in ("gu_cold", "gu_prefetched", "pf_only"):
+    # does an Infinity-Cache-resident weight matrix stream faster?  28 different (2I, H) matrices (1.5 GB, far beyond the cache),
+    # graph-replayed: gate/up alone, prefetch kernel + gate/up, prefetch kernel alone
+    H, I = 1536, 8960
+    Ws = [r(2 * I, H) for _ in range(28)]
+    x, lnw, h = r(H), r(H), torch.empty(I, dtype=bf, device=dev)
+    nwg = int(os.environ.get("MB_PF_WGS", 1024))
+    def layers():
+        for W in Ws:
+            if which != "gu_cold":
+                o.prefetch(W, nwg)
+            if which != "pf_only":
+                o.dec_gate_up(x, lnw, 1e-6, W, h)
+    layers(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        layers()
+    fn = g.replay
 elif which == "resize":
     # one chunk of a 720p source at 2 fps: (2, 3, 720, 1280) uint8 -> (2, 3, 560, 1008), the reference's smart-resized size
     src = torch.randint(0, 256, (2, 3, 720, 1280), dtype=torch.uint8, device=dev)
