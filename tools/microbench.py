@@ -37,8 +37,9 @@ elif which == "decode_attn":
     slot = torch.arange(2560, dtype=torch.int32, device=dev)
     rope = r(2560, 128)
     q, out = r(Hq * 128), torch.empty(Hq * 128, dtype=bf, device=dev)
-    ws = o.decode_attn_ws(Hq, 2560, 32, dev)
-    fn = lambda: o.decode_attn(q, pool, 0, slot, rope, out, ws, Hq, 2560, 32, 128 ** -0.5, length=L)
+    ch = int(os.environ.get("MB_CHUNK", 48))          # keys per workgroup: the engine's choice for bounded windows
+    ws = o.decode_attn_ws(Hq, 2560, ch, dev)
+    fn = lambda: o.decode_attn(q, pool, 0, slot, rope, out, ws, Hq, 2560, ch, 128 ** -0.5, length=L)
 elif which == "dec_gate_up":
     # 28 DIFFERENT weight matrices (1.5 GB > Infinity Cache), like the 28 layers of a decode step
     H, I = 1536, 8960
