@@ -40,14 +40,19 @@ class GenOut:
     sequences: List[int]
     past_key_values: object
     logits: List[torch.Tensor] = field(default_factory=list)   # fp32 raw last-row logits per step
+    own: List[int] = field(default_factory=list)               # the token each step chose itself (differs from the sequence under force_tokens)
+    n_generated: int = 0
 
 
 def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=None, grid_thw=None,
              max_new_tokens=20, rep_penalty=1.05, eos_ids=(151645, 151643), suppress_eos=False,
              do_sample=False, temperature=1.0, generator: Optional[torch.Generator] = None,
-             keep_logits=False, all_text=False, second_per_grid_t=1.0, pos_mode="shrink", sargs: Optional[dict] = None) -> GenOut:
+             keep_logits=False, all_text=False, second_per_grid_t=1.0, pos_mode="shrink", sargs: Optional[dict] = None,
+             force_tokens: Optional[List[int]] = None) -> GenOut:
     """One ``model.generate(**inputs, past_key_values=kv, streaming_args=...)`` call.  `sargs` is the part of StreamingArgs
-    that outlives a call: {"last_cache_position": int} (streaming_args.py:9, used by pos_mode="append")."""
+    that outlives a call: {"last_cache_position": int} (streaming_args.py:9, used by pos_mode="append").
+    `force_tokens` (test aid, not in the reference): teacher forcing -- each step's own choice is recorded in `.own` and the
+    given token is appended instead, so two arithmetic variants can be compared forward by forward on one history."""
     if sargs is None:
         sargs = {"last_cache_position": -1}
 
@@ -62,8 +67,11 @@ def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=
     ids = list(ids)
     sa_ids = list(ids)                       # streaming_args.input_ids (padded with 0 per forward)
     out_logits = []
+    own = []
     n_new = 0
     first = True
+    if force_tokens is not None:
+        max_new_tokens = len(force_tokens)
     while True:
         kv_len = kv.get_seq_length()
         new_ids = ids[kv_len:]                                              # prepare_generation.py:31-35
@@ -96,11 +104,14 @@ def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=
             nxt = int(torch.multinomial(probs, 1, generator=generator))
         else:
             nxt = int(torch.argmax(sc))                                     # :99
+        own.append(nxt)
+        if force_tokens is not None:
+            nxt = int(force_tokens[n_new])
         ids.append(nxt)
         n_new += 1
         if nxt in eos_ids or n_new >= max_new_tokens:                       # :101-109
             break
-    return GenOut(ids, kv, out_logits)
+    return GenOut(ids, kv, out_logits, own, n_new)
 
 
 @dataclass
@@ -124,7 +135,7 @@ class StreamCfg:
 
 
 def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
-                   chunk_source: Callable[[int], tuple], keep_logits=False):
+                   chunk_source: Callable[[int], tuple], keep_logits=False, force_tokens: Optional[List[List[int]]] = None):
     """The loop of inference.py:309-517 on synthetic inputs.
 
     chunk_source(i) -> (chunk_ids: list[int], pixel_values (N,1176), grid_thw [[t,h,w]])
@@ -134,7 +145,7 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
     prev_ids: Optional[List[int]] = None
     sargs = {"last_cache_position": -1}                                     # StreamingArgs lives for the whole stream (inference.py:213)
     grids: List[List[int]] = []
-    trace, new_tokens, kv_lens, all_logits, ids_hist = [], [], [], [], []
+    trace, new_tokens, kv_lens, all_logits, ids_hist, own_hist, generated = [], [], [], [], [], [], []
     for i in range(n_chunks):
         chunk_trace = []
         # ---- process_past_kv (inference.py:319)
@@ -159,8 +170,11 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
         cur_len = len(ids)
         out = generate(w, cfg, ids, kv, grids, pix, grid, scfg.max_new_tokens, scfg.repetition_penalty,
                        suppress_eos=scfg.suppress_eos, keep_logits=keep_logits, all_text=scfg.all_text,
-                       second_per_grid_t=scfg.second_per_grid_t, pos_mode=scfg.pos_mode, sargs=sargs)
+                       second_per_grid_t=scfg.second_per_grid_t, pos_mode=scfg.pos_mode, sargs=sargs,
+                       force_tokens=None if force_tokens is None else force_tokens[i])
         gen = out.sequences
+        own_hist.append(out.own)
+        generated.append(gen[cur_len:])                                     # without the appended <|im_end|>
         if gen[-1] != qr.IM_END:                                            # :457-459
             gen = gen + [qr.IM_END]
         new_tokens.append(gen[cur_len:])
@@ -168,4 +182,5 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
         all_logits.append(out.logits)
         prev_ids = list(gen)                                                # :482
         ids_hist.append(list(gen))
-    return dict(ids=ids_hist, new_tokens=new_tokens, kv_len=kv_lens, trace=trace, logits=all_logits, kv=kv)
+    return dict(ids=ids_hist, new_tokens=new_tokens, kv_len=kv_lens, trace=trace, logits=all_logits, kv=kv, own=own_hist,
+                generated=generated)

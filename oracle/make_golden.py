@@ -231,12 +231,24 @@ def gen_hf_vectors_2_5():
 
 
 def gen_oracle_vectors():
+    """Oracle streams on the DECISIVE weights (streaming_vlm_amd.weights.decisive_state_dict with the copy distance
+    tests/helpers.py:decisive_offset picks for the stream's geometry): every greedy token is decided by a margin far above the
+    bf16 noise of any implementation, so the GPU replay (tests/test_engine_gpu.py) demands token-for-token equality."""
     import helpers as H
     from streaming_vlm_amd import config as C
-    from streaming_vlm_amd.weights import random_state_dict
     cfg = C.tiny()
-    sd = random_state_dict(cfg, 0, "cpu")
     runs = {}
+
+    def mint(name, cfg, kw, n, model=None):
+        sd = H.decisive_weights(cfg, size=kw.get("size", 56), all_text=kw.get("all_text", False))
+        o = H.run_oracle_stream(cfg, sd, n, keep_logits=True, **kw)
+        mm = min(H.greedy_margins(o))
+        assert mm >= 0.5, (name, mm)
+        runs[name] = {"kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"],
+                      "min_margin": round(mm, 4), "offset": H.decisive_offset(kw.get("size", 56), 8, kw.get("all_text", False))}
+        if model:
+            runs[name]["model"] = model
+
     for name, kw in {
         "sink4_win64": dict(policy="sink_window", sink=4, window=64),
         "sink4_win256": dict(policy="sink_window", sink=4, window=256, size=112),
@@ -252,12 +264,9 @@ def gen_oracle_vectors():
         "append_structural_t2_v3": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
                                         previous_text="a b c d e f g h i j k l m n o p", pos_mode="append"),
     }.items():
-        n = 20 if "default" in name else (32 if name.startswith("cfg0") else 10)
-        o = H.run_oracle_stream(cfg, sd, n, **kw)
-        runs[name] = {"kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"]}
+        mint(name, cfg, kw, 20 if "default" in name else (32 if name.startswith("cfg0") else 10))
     # Qwen2.5-VL family (tiny_2_5: windowed RMSNorm/SwiGLU tower, float temporal M-RoPE); frames of 112x84 have ragged windows
     cfg25 = C.tiny_2_5()
-    sd25 = random_state_dict(cfg25, 0, "cpu")
     for name, kw in {
         "q25_sink4_win64": dict(policy="sink_window", sink=4, window=64),
         "q25_ragged_sink4_win96": dict(policy="sink_window", sink=4, window=96, size=[112, 84]),
@@ -267,12 +276,45 @@ def gen_oracle_vectors():
         "q25_append_structural": dict(policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
                                       previous_text="a b c d e f g h i j k l m n o p", pos_mode="append"),
     }.items():
-        o = H.run_oracle_stream(cfg25, sd25, 10, **kw)
-        runs[name] = {"model": "tiny_2_5", "kwargs": kw, "n_chunks": 10, "trace": o["trace"], "kv_len": o["kv_len"],
-                      "new_tokens": o["new_tokens"]}
+        mint(name, cfg25, kw, 10, model="tiny_2_5")
     with open(os.path.join(OUT, "oracle_streams.json"), "w") as f:
         json.dump(runs, f)
-    print("oracle vectors:", list(runs))
+    print("oracle vectors:", {k: v["min_margin"] for k, v in runs.items()})
+
+
+def gen_full_size_vectors(which=("2b", "7b")):
+    """FULL-size token streams (tests/golden/full_size_streams.json): the CPU oracle in bf16 on the decisive weights, minutes of
+    host time each, so they are minted here once and replayed on the GPU without the oracle in the loop.
+      cfg1_2b_448_win2048   BASELINE configs[1]: Qwen2-VL-2B, 448x448 @1 fps, sink 4 / window 2048, 20 tokens, 12 chunks
+                            (the window fills at chunk 7 and evicts from there on)
+      cfg2_7b_448_2fps      configs[2]'s model and frame rate: Qwen2-VL-7B, 448x448 @2 fps, 20 tokens, window 512, 3 chunks
+    Stored per chunk: eviction trace, KV length, tokens, and the raw logit of each chosen token (to bound the GPU's logit there)."""
+    import helpers as H
+    from streaming_vlm_amd import config as C
+    path = os.path.join(OUT, "full_size_streams.json")
+    runs = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            runs = json.load(f)
+    plans = {"2b": ("cfg1_2b_448_win2048", C.qwen2_vl_2b, dict(size=448, fps=1.0, policy="sink_window", sink=4, window=2048, max_new=20,
+                                                              previous_text=""), 12),
+             "7b": ("cfg2_7b_448_2fps", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=512, max_new=20,
+                                                           previous_text=""), 3)}
+    for key in which:
+        name, mk, kw, n = plans[key]
+        cfg = mk()
+        sd = H.decisive_weights(cfg, size=kw["size"], max_new=kw["max_new"])
+        o = H.run_oracle_stream(cfg, sd, n, keep_logits=True, **kw)
+        mm = min(H.greedy_margins(o))
+        assert mm >= 1.0, (name, mm)
+        tops = [[round(float(lg[t]), 4) for lg, t in zip(lgs, gen)] for lgs, gen in zip(o["logits"], o["generated"])]
+        runs[name] = {"model": key, "kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"],
+                      "top_logit": tops, "min_margin": round(mm, 4), "max_len": kw["sink"] + kw["window"] + 2 * 320 + 64,
+                      "torch": torch.__version__}
+        print(name, "min margin", mm, "kv_len", o["kv_len"])
+        del sd, o
+        with open(path, "w") as f:
+            json.dump(runs, f)
 
 
 if __name__ == "__main__":
@@ -282,3 +324,5 @@ if __name__ == "__main__":
     gen_hf_vectors()
     gen_hf_vectors_2_5()
     gen_oracle_vectors()
+    if "--full" in sys.argv:          # minutes of CPU time and ~20 GB of RAM for the 7B
+        gen_full_size_vectors()

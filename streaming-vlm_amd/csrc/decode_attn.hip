@@ -408,17 +408,23 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
   }
   const int L = (len_dev ? *len_dev : 0) + len_add;
   const int ns = (L + chunk - 1) / chunk;
-  // global max over splits (every wave computes it redundantly: ns floats)
-  float mx = -1e30f;
-  for (int i = lane; i < ns; i += 64) mx = fmaxf(mx, ws_m[(size_t)i * Hq + hq]);
-  __builtin_amdgcn_sched_barrier(0);
-  mx = wave_max(mx);
-  float l = 0.f, a0 = 0.f, a1 = 0.f;
+  // Online merge: the running maximum of a wave comes from the m values it already holds in registers (one DPP/permlane
+  // reduction per batch), not from a second pass over ws_m -- that pass was a dependent round trip to another CU's partials
+  // behind the length, as long as the whole first batch.  The waves' (m, l, acc) triples meet in LDS below.
+  float mrun = -1e30f, l = 0.f, a0 = 0.f, a1 = 0.f;
   for (int base = 0;;) {
+    float bm = -1e30f;
+#pragma unroll
+    for (int u = 0; u < DA_CB; ++u)
+      if (base + first + STRIDE * u < ns) bm = fmaxf(bm, m_[u]);
+    const float mnew = fmaxf(mrun, wave_max(bm));
+    const float alpha = __expf(mrun - mnew);
+    l *= alpha; a0 *= alpha; a1 *= alpha;
+    mrun = mnew;
 #pragma unroll
     for (int u = 0; u < DA_CB; ++u) {
       if (base + first + STRIDE * u < ns) {
-        const float e = __expf(m_[u] - mx);
+        const float e = __expf(m_[u] - mrun);
         l += l_[u] * e;
         a0 += v_[u].x * e;
         a1 += v_[u].y * e;
@@ -436,12 +442,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  // fold the sub-slots of the wave (lanes cl, cl + CW, ...), then the waves through LDS
+  // fold the sub-slots of the wave (lanes cl, cl + CW, ...; they share mrun), then the waves through LDS
   if constexpr (DS >= 2) { l += __shfl_xor(l, 32, 64); a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64); }
   if constexpr (DS >= 4) { l += __shfl_xor(l, 16, 64); a0 += __shfl_xor(a0, 16, 64); a1 += __shfl_xor(a1, 16, 64); }
+  __shared__ float sm[NW];
   __shared__ float sl[NW];
   __shared__ float sa[NW][DA_D / DS];
-  if (lane == 0) sl[wave] = l;
+  if (lane == 0) { sm[wave] = mrun; sl[wave] = l; }
   if (sub == 0) {
     sa[wave][2 * cl] = a0;
     sa[wave][2 * cl + 1] = a1;
@@ -449,11 +456,15 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
   __syncthreads();
   if (threadIdx.x < DA_D / DS) {
     const int d = threadIdx.x;
+    float mt = sm[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mt = fmaxf(mt, sm[w]);
     float lt = 0.f, at = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      lt += sl[w];
-      at += sa[w][d];
+      const float e = __expf(sm[w] - mt);          // a wave without a live split holds (-1e30, 0, 0): e underflows to 0
+      lt += sl[w] * e;
+      at += sa[w][d] * e;
     }
     out[(size_t)hq * DA_D + blockIdx.y * (DA_D / DS) + d] = f2bf(at / lt);
   }

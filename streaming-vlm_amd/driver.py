@@ -162,9 +162,34 @@ def process_past_kv(past_key_values, i, text_round, visual_round, full_conversat
 
 
 # ----------------------------------------------------------------------------- loading
-def load_model_and_processor(model_path, model_base="Qwen2_5"):
+def required_max_len(tokens_per_chunk, max_new_tokens=MAX_TOKEN_PER_DURATION, kv_policy="structural", window_size=DEFAULT_WINDOW_SIZE,
+                     text_round=DEFAULT_TEXT_ROUND, text_sink=None, text_sliding_window=None, sink=4, window=2048, num_chunks=TOTAL_VIDEO_DURATION,
+                     previous_text_tokens=0, query_tokens=8) -> int:
+    """Largest logical sequence (cached rows + un-cached suffix + generated tokens) a stream with these settings reaches: the
+    `max_len` its engine needs (rope table, slot table, KV pool).  The reference grows torch tensors as it goes; here HBM is
+    sized once, for the whole stream, from the eviction policy."""
+    chunk = int(tokens_per_chunk) + 24 + int(max_new_tokens) + 2        # user header + vision span + assistant turn
+    head = 16 + query_tokens                                            # system prompt, first chunk's query
+    if kv_policy == "sink_window":
+        return sink + window + 2 * chunk + head
+    grown = previous_text_tokens + num_chunks * (max_new_tokens + 1)     # what the previous-text block can have absorbed by the end
+    if kv_policy == "none":
+        return head + previous_text_tokens + (num_chunks + 1) * chunk
+    pt = grown if (text_sink is None or text_sliding_window is None) else min(grown, text_sink + text_sliding_window + 12)
+    rounds_v, rounds_t = min(window_size, num_chunks), min(text_round, num_chunks)
+    return head + pt + 8 + rounds_v * (int(tokens_per_chunk) + 24) + rounds_t * (max_new_tokens + 6) + chunk + max_new_tokens
+
+
+def load_model_and_processor(model_path, model_base="Qwen2_5", max_len=None, max_new_tokens=None):
     """HF checkpoint -> converted model + AutoProcessor (needs local weights; nothing is downloaded).
-    ``random:<2b|7b|tiny>[:seed]`` builds random-init weights of the real shapes with the synthetic processor."""
+    ``random:<2b|7b|tiny>[:seed]`` builds random-init weights of the real shapes with the synthetic processor.
+    `max_len` / `max_new_tokens` size the engine (see `required_max_len`; `streaming_inference` derives them from its own
+    arguments when it loads the model itself)."""
+    ekw = {}
+    if max_len is not None:
+        ekw["max_len"] = int(max_len)
+    if max_new_tokens is not None:
+        ekw["max_new_tokens"] = int(max_new_tokens)
     if model_path.startswith("random:"):
         from . import config as C
         from .weights import random_state_dict
@@ -172,17 +197,17 @@ def load_model_and_processor(model_path, model_base="Qwen2_5"):
         cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "tiny": C.tiny, "2.5-3b": C.qwen2_5_vl_3b, "2.5-7b": C.qwen2_5_vl_7b,
                "tiny-2.5": C.tiny_2_5}[parts[1]]()
         seed = int(parts[2]) if len(parts) > 2 else 0
-        return StreamingQwen2VL(cfg, random_state_dict(cfg, seed, "cuda"), "cuda"), SyntheticProcessor()
+        return StreamingQwen2VL(cfg, random_state_dict(cfg, seed, "cuda"), "cuda", **ekw), SyntheticProcessor()
     from transformers import AutoProcessor
     if model_base == "Qwen2_5":                        # reference inference.py:72-78
         from transformers import Qwen2_5_VLForConditionalGeneration
         model = Qwen2_5_VLForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map="cuda")
-        return convert_qwen2_5_to_streaming(model), AutoProcessor.from_pretrained(model_path, use_fast=False)
+        return convert_qwen2_5_to_streaming(model, **ekw), AutoProcessor.from_pretrained(model_path, use_fast=False)
     if model_base != "Qwen2":
         raise ValueError(f"model_base must be 'Qwen2' or 'Qwen2_5', not {model_base!r}")
     from transformers import Qwen2VLForConditionalGeneration
     model = Qwen2VLForConditionalGeneration.from_pretrained(model_path, torch_dtype="auto", device_map="cuda")
-    return convert_qwen2_to_streaming(model), AutoProcessor.from_pretrained(model_path, use_fast=False)
+    return convert_qwen2_to_streaming(model, **ekw), AutoProcessor.from_pretrained(model_path, use_fast=False)
 
 
 def printq(*args, quiet=False, **kwargs):
@@ -211,7 +236,8 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         emit_json=False, time_test=False, *, kv_policy="structural", sink=4, window=2048, do_sample=True,
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
-                        generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True):
+                        generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True, force_tokens=None,
+                        max_len=None):
     # The reference synchronises the device around every section to print per-section times.  Nobody reads them when the
     # loop is quiet and not under time_test, and each of the dozen syncs per chunk is host time the GPU spends idle.
     timed_sections = time_test or not quiet
@@ -228,12 +254,40 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         raise ValueError(f"unknown kv_policy {kv_policy!r}")
 
     streaming_args = StreamingArgs(pos_mode=pos_mode, all_text=all_text)
+    if video is None:
+        video = SyntheticVideo.from_path(video_path)
+    if video is None:
+        raise FileNotFoundError(
+            f"{video_path!r}: real video decode (decord + bicubic resize) is host I/O outside the hot path; "
+            f"pass video=<object with .chunk(start_s, duration_s) -> uint8 (T,3,H,W)> or a synthetic://WxH@Ffps path")
+    num_chunks = int((duration + chunk_duration - 1) // chunk_duration)
+
+    def engine_len(proc):
+        """`max_len` for an engine built HERE: the policy's bound with the token count of the stream's first chunk."""
+        if max_len is not None:
+            return int(max_len)
+        from .ingest import resized_shape
+        f0 = video.chunk(skip_first_chunk * chunk_duration, chunk_duration)
+        h, w = f0.shape[2], f0.shape[3]
+        if getattr(video, "spatial_resize", False):
+            h, w = resized_shape(h, w, f0.shape[0])
+        n_tok = ((f0.shape[0] + 1) // 2) * (h // 28) * (w // 28)
+        n_prev = len(proc(text=previous_text)["input_ids"][0]) if previous_text else 0
+        return required_max_len(n_tok, max_new_tokens, kv_policy, window_size // chunk_duration, text_round, text_sink, text_sliding_window,
+                                sink, window, num_chunks, n_prev)
+
     if model is None or processor is None:
-        model, processor = load_model_and_processor(model_path, model_base)
+        if model_path.startswith("random:") or processor is not None:
+            model, processor = load_model_and_processor(model_path, model_base, engine_len(processor or SyntheticProcessor()), max_new_tokens)
+        else:           # the checkpoint's own processor is only known once it is loaded
+            from transformers import AutoProcessor
+            processor = AutoProcessor.from_pretrained(model_path, use_fast=False)
+            model, _ = load_model_and_processor(model_path, model_base, engine_len(processor), max_new_tokens)
     elif getattr(model, "_svlm_engine", None) is None:
         if model_base not in ("Qwen2", "Qwen2_5"):
             raise ValueError(f"model_base must be 'Qwen2' or 'Qwen2_5', not {model_base!r}")
-        model = (convert_qwen2_5_to_streaming if model_base == "Qwen2_5" else convert_qwen2_to_streaming)(model)
+        model = (convert_qwen2_5_to_streaming if model_base == "Qwen2_5" else convert_qwen2_to_streaming)(
+            model, max_len=engine_len(processor), max_new_tokens=max_new_tokens)
     device = model.device
 
     assistant_start_bias = len(processor(text="<|im_start|>assistant\n")["input_ids"][0])
@@ -247,13 +301,6 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                     gt_dict = json.loads(line)
                     break
 
-    if video is None:
-        video = SyntheticVideo.from_path(video_path)
-    if video is None:
-        raise FileNotFoundError(
-            f"{video_path!r}: real video decode (decord + bicubic resize) is host I/O outside the hot path; "
-            f"pass video=<object with .chunk(start_s, duration_s) -> uint8 (T,3,H,W)> or a synthetic://WxH@Ffps path")
-
     if output_dir is not None:
         if os.path.exists(output_dir):
             os.remove(output_dir)
@@ -265,7 +312,6 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
     full_conversation_history = []
     prev_generated_ids = None
     recent_video_window_clips, recent_pixel_values_videos = [], []
-    num_chunks = int((duration + chunk_duration - 1) // chunk_duration)
     responses, time_results = [], []
     printq(f"num_chunks: {num_chunks}", quiet=quiet)
 
@@ -363,6 +409,8 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                       temperature=temperature, suppress_eos=suppress_eos, generator=generator, keep_logits=keep_logits)
         if lookahead is not None:
             gen_kw["next_vision"] = (lookahead[1], lookahead[2])
+        if force_tokens is not None:          # parity tests: per-chunk teacher forcing (engine.generate)
+            gen_kw["force_tokens"] = force_tokens[i]
         if recompute:
             if past_key_values is not None:
                 past_key_values.release_reserved()
@@ -391,7 +439,8 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
             token_counts.append(int(n_decoded))
         if ids_log is not None:
             ids_log.append({"ids": generated_ids[0].tolist(), "new": newly_generated_ids[0].tolist(),
-                            "kv_len": outputs.past_key_values.get_seq_length(), "logits": getattr(outputs, "logits", None)})
+                            "kv_len": outputs.past_key_values.get_seq_length(), "logits": getattr(outputs, "logits", None),
+                            "own": getattr(outputs, "own", None)})
         time_key = prompt
         past_key_values = outputs.past_key_values
         hms = lambda s: time.strftime("%H:%M:%S", time.gmtime(int(s)))
@@ -463,6 +512,8 @@ def _cli(argv=None):
     ap.add_argument("--sink", type=int, default=4)
     ap.add_argument("--window", type=int, default=2048)
     ap.add_argument("--greedy", action="store_true", help="do_sample=False")
+    ap.add_argument("--max_len", type=int, default=None, help="engine capacity in tokens (default: derived from the eviction policy)")
+    ap.add_argument("--max_new_tokens", type=int, default=MAX_TOKEN_PER_DURATION)
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args(argv)
     kw = dict(vars(a))

@@ -36,6 +36,7 @@ class GenerateOutput:
     past_key_values: KVPool
     logits: Optional[List[torch.Tensor]] = None      # fp32 last-row logits per forward (tests)
     n_new: int = 0
+    own: Optional[List[int]] = None                  # with force_tokens: the engine's own greedy choice at every step
 
 
 def _window_plan(grid, merge: int, window_size: int, patch: int):
@@ -450,9 +451,12 @@ class SvlmEngine:
                  max_new_tokens: int = 20, repetition_penalty: float = 1.05, do_sample: bool = False, temperature: float = 1.0,
                  suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
                  all_text: bool = False, second_per_grid_t: Optional[float] = None, pos_mode: str = "shrink",
-                 last_cache_position: float = -1) -> GenerateOutput:
+                 last_cache_position: float = -1, force_tokens: Optional[Sequence[int]] = None) -> GenerateOutput:
         """`next_vision=(pixel_values, grid_thw)` of the FOLLOWING chunk, when the caller already has its frames, is
-        encoded on a side stream underneath this chunk's decode steps (see `vision_prefetch`)."""
+        encoded on a side stream underneath this chunk's decode steps (see `vision_prefetch`).
+        `force_tokens` (greedy only): teacher forcing for parity tests -- every step still takes its own argmax on the device
+        (returned in `.own`), then the given token is fed back instead, so that the logits of EVERY forward can be compared
+        with a reference even after a near-tie went the other way."""
         cfg, tc, o = self.cfg, self.cfg.text, self.ops
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
         if cache is None:
@@ -542,12 +546,21 @@ class SvlmEngine:
                 self.vision_prefetch(*next_vision)
             return self._generate_sampling(ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out, L_before, pos_full)
         self._sample_launch(0)
+        own = None
+        if force_tokens is not None:
+            if len(force_tokens) < 1 or len(force_tokens) > max_new_tokens:
+                raise ValueError(f"force_tokens has {len(force_tokens)} entries for max_new_tokens={max_new_tokens}")
+            max_new_tokens = len(force_tokens)
+            own, seen_host = [], set(int(t) for t in ids)
+            self._force(0, force_tokens, own, seen_host)
         if next_vision is not None:
             self.vision_prefetch(*next_vision)
-        for _ in range(1, max_new_tokens):
+        for step in range(1, max_new_tokens):
             self._decode_step(cache)
             if keep_logits:
                 logits_out.append(self.logits.detach().cpu().clone())
+            if own is not None:
+                self._force(step, force_tokens, own, seen_host)
         # the one host sync of the chunk waits for the TOKENS only: the held-back ViT tail of the look-ahead pass is enqueued
         # behind the copy and keeps the GPU busy while the host turns the chunk around
         if self.device.type == "cuda":
@@ -568,7 +581,19 @@ class SvlmEngine:
         cache.pos_rows[:, L_before:cache.length] = pos_full[:, L_before:cache.length]
         self.last_position = float(pos_full[0, cache.length - 1])           # streaming_args.last_cache_position
         seq = ids.tolist() + [int(t) for t in toks[:n_new]]
-        return GenerateOutput(seq, cache, logits_out, n_new)
+        return GenerateOutput(seq, cache, logits_out, n_new, own)
+
+    def _force(self, step: int, force_tokens, own: list, seen_host: set):
+        """Teacher forcing: note the token the device just chose for `step`, put the given one in its place."""
+        mine, tok = int(self.tok_buf[step]), int(force_tokens[step])
+        own.append(mine)
+        if mine != tok:
+            self.tok_buf[step:step + 1].copy_(torch.tensor([tok], dtype=torch.int32))
+            if self._penalty != 1.0:
+                if mine not in seen_host:
+                    self.seen[mine] = 0
+                self.seen[tok] = 1
+        seen_host.add(tok)
 
     def _generate_sampling(self, ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out, L_before, pos_full):
         """do_sample=True (the reference's default: T=0.9, multinomial, streaming_generate_qwen.py:95-97).

@@ -39,7 +39,8 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
                        past_key_values=None, max_new_tokens: int = 20, use_cache: bool = True,
                        return_dict_in_generate: bool = True, do_sample: bool = True, repetition_penalty: float = 1.0,
                        streaming_args: Optional[StreamingArgs] = None, pad_token_id=None, temperature: float = 1.0,
-                       second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None, **unused):
+                       second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
+                       force_tokens=None, **unused):
     """Greedy / sampling generation on the HIP engine (reference: streaming_generate + _sample,
     generate/streaming_generate_qwen.py:130-278, 8-127)."""
     eng: SvlmEngine = self._svlm_engine
@@ -58,7 +59,7 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
                        repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision,
                        all_text=bool(streaming_args.all_text), pos_mode=streaming_args.pos_mode,
-                       last_cache_position=streaming_args.last_cache_position)
+                       last_cache_position=streaming_args.last_cache_position, force_tokens=force_tokens)
     streaming_args.last_cache_position = eng.last_position          # qwen2/model_forward.py:117
     # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)
     if streaming_args.input_ids is not None:
@@ -66,7 +67,7 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     seq = torch.tensor([out.sequences], dtype=torch.long, device=input_ids.device)
     if not return_dict_in_generate:
         return seq
-    return SimpleNamespace(sequences=seq, past_key_values=out.past_key_values, logits=out.logits, n_new=out.n_new)
+    return SimpleNamespace(sequences=seq, past_key_values=out.past_key_values, logits=out.logits, n_new=out.n_new, own=out.own)
 
 
 class StreamingQwen2VL:

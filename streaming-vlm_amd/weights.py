@@ -78,6 +78,58 @@ def random_state_dict(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch
     return sd
 
 
+def decisive_state_dict(cfg: ModelConfig, seed: int = 0, device="cpu", dtype=torch.bfloat16, offset: int = 45,
+                        gain: float = 20.0, sharpness: float = 4.0):
+    """Random weights of the real shapes whose GREEDY TOKEN is decided by a wide margin (tens of times the bf16 noise of a
+    28-layer forward) while still depending on the cached context: `random_state_dict` plus one planted attention head.
+
+    With iid random weights the top two of ~152k logits are closer than the rounding noise in a fixed fraction of the
+    steps whatever the kernels do, so "token ids exact under greedy" cannot be asserted on them.  The planted head makes
+    the network digital the way a trained copy/induction head is:
+      * layer 0, kv head 0 and its query heads: q and k come from their BIASES only (weights zeroed) and carry one
+        amplitude on the 16 temporal M-RoPE frequency pairs, phased so that after the rotation q(p) . k(p') peaks at
+        p - p' == `offset` (`sharpness` = score gap per unit of sum(cos): 1.35 units to the neighbours, > 4.6 beyond);
+      * its value / output projections are gamma * P^T P with one random P (128 x hidden): the head writes a copy of the
+        (layer-0, i.e. exact) embedding of the token `offset` positions back into the residual stream with RMS `gain`;
+      * the tied lm_head reads that copy back as the same token (the 7B's separate lm_head is set equal to the embedding);
+      * the chat-template markers the span finder keys on (<|im_start|>, <|im_end|>, <|endoftext|>, the vision markers, "Time")
+        are embedded as HALF the embedding of an ordinary stand-in token, so a copied marker decodes to its stand-in and
+        the generated text never contains one.
+    Every other weight, the whole ViT included, stays N(0, 0.02) and runs at its usual magnitudes; which token comes out
+    depends on the KV row `offset` positions back, its slot mapping and its re-indexed position."""
+    from .config import ENDOFTEXT, IM_END, IM_START, VIDEO_PAD, VISION_END, VISION_START
+    tc = cfg.text
+    sd = random_state_dict(cfg, seed, device, dtype)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 7919)
+    D, H, G = tc.head_dim, tc.hidden_size, tc.num_heads // tc.num_kv_heads
+    n_t = tc.mrope_section[0]                                   # temporal frequency pairs: text tokens' 1-D positions
+    inv = 1.0 / (tc.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float64) / D))
+    amp = (sharpness * (D ** 0.5)) ** 0.5                       # b^2 * sum(cos) / sqrt(D) = sharpness * sum(cos)
+    kb = torch.zeros(D, dtype=torch.float64)
+    qb = torch.zeros(D, dtype=torch.float64)
+    kb[:n_t] = amp
+    qb[:n_t] = amp * torch.cos(inv[:n_t] * offset)
+    qb[D // 2:D // 2 + n_t] = -amp * torch.sin(inv[:n_t] * offset)
+    p = f"{L_PREFIX}layers.0.self_attn."
+    sd[p + "q_proj.weight"][:G * D] = 0
+    sd[p + "k_proj.weight"][:D] = 0
+    sd[p + "q_proj.bias"][:G * D] = qb.float().repeat(G).to(device=device, dtype=dtype)
+    sd[p + "k_proj.bias"][:D] = kb.float().to(device=device, dtype=dtype)
+    P = torch.randn((D, H), generator=g, device=device, dtype=torch.float32) * 0.02
+    sd[p + "v_proj.weight"][:D] = P.to(dtype)
+    sd[p + "v_proj.bias"][:D] = 0
+    # |P^T P x| for a unit-RMS x: sigma^2 * sqrt(D^2 + D*H) per coordinate
+    gamma = gain / (0.02 ** 2 * (D * D + D * H) ** 0.5)
+    sd[p + "o_proj.weight"][:, :G * D] = ((gamma / G) * P.t().repeat(1, G)).to(dtype)
+    emb = sd[L_PREFIX + "embed_tokens.weight"]
+    for k, s in enumerate((ENDOFTEXT, IM_START, IM_END, VISION_START, VISION_END, VIDEO_PAD, 1462)):      # 1462 = "Time", a span marker
+        emb[s] = (0.5 * emb[1000 + 37 * k].float()).to(dtype)
+    if not tc.tie_word_embeddings:
+        sd["lm_head.weight"] = emb.clone()
+    return sd
+
+
 class EngineWeights:
     """Fused, contiguous, device-resident views the kernels consume."""
 

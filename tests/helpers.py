@@ -41,11 +41,41 @@ def chunk_source(proc, video, previous_text="", query="Commentate on this match"
 
 
 def run_oracle_stream(cfg, sd, n_chunks, size=56, fps=1.0, policy="sink_window", sink=4, window=64, max_new=8, suppress_eos=True,
-                      previous_text="hello world", keep_logits=False, **policy_kw):
+                      previous_text="hello world", keep_logits=False, force_tokens=None, **policy_kw):
     proc = S.SyntheticProcessor()
     video = S.SyntheticVideo(size, fps, 0)
     scfg = og.StreamCfg(policy=policy, sink=sink, window=window, max_new_tokens=max_new, suppress_eos=suppress_eos, **policy_kw)
-    return og.streaming_loop(sd, oracle_cfg(cfg), scfg, n_chunks, chunk_source(proc, video, previous_text), keep_logits=keep_logits)
+    return og.streaming_loop(sd, oracle_cfg(cfg), scfg, n_chunks, chunk_source(proc, video, previous_text), keep_logits=keep_logits,
+                             force_tokens=force_tokens)
+
+
+def decisive_offset(size=56, max_new=8, all_text=False):
+    """Copy distance of `weights.decisive_state_dict` for a stream geometry: far enough back that no decode step of a chunk
+    (the first chunk carries 4 query tokens more) looks at the chunk's own vision span, whose rows all share one temporal
+    position (M-RoPE) and hold ViT features, not token embeddings."""
+    h, w = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    gh, gw = h // 28, w // 28
+    return (gh * gw if all_text else max(gh, gw)) + max_new + 12
+
+
+def decisive_weights(cfg, size=56, max_new=8, all_text=False, seed=0, **_):
+    from streaming_vlm_amd.weights import decisive_state_dict
+    return decisive_state_dict(cfg, seed, "cpu", offset=decisive_offset(size, max_new, all_text))
+
+
+def greedy_margins(ref, suppress_eos=True, penalty=1.05):
+    """Top-2 margin of the score that decides each greedy token of an oracle stream: AFTER the repetition penalty and the EOS
+    suppression (streaming_generate_qwen.py:75-99)."""
+    out = []
+    for ids, gen, logits in zip(ref["ids"], ref["generated"], ref["logits"]):
+        n_prompt = len(ids) - len(gen) - (1 if len(ids) and ids[-1] == 151645 and (not gen or gen[-1] != 151645) else 0)
+        for j, b in enumerate(logits):
+            sc = og.repetition_penalty(b.clone(), ids[:n_prompt + j], penalty)
+            if suppress_eos:
+                sc[[151645, 151643]] = float("-inf")
+            top2 = torch.topk(sc, 2).values
+            out.append(float(top2[0] - top2[1]))
+    return out
 
 
 def run_engine_stream(model, n_chunks, size=56, fps=1.0, policy="sink_window", sink=4, window=64, max_new=8, suppress_eos=True,

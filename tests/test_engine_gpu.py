@@ -1,16 +1,19 @@
 """GPU end-to-end parity: the streaming loop on HIP kernels vs the CPU oracle on the same synthetic
 stream and the same seeded weights.
 
-Bars
+Bars (north_star: "logits within 1e-3 bf16, token ids exact under greedy, identical eviction indices")
   * eviction traces (every prune/move with its closed interval) and KV lengths: identical;
-  * last-row logits of every forward: both sides round to bf16 at the same ~12 points per layer, and
-    flash attention rounds P = exp(s - running max) to bf16 tile by tile, so ANY two valid tilings differ by
-    single bf16 flips that propagate through the layers.  The test measures that floor on the oracle itself
-    (global-max vs 32-key tiles) and requires the HIP path to stay within 2.5x of it
-    (mean|d|/max|ref| <= 2.5*floor + 5e-4, max <= 2.5*floor + 5e-3; DESIGN.md "Numerics");
-  * greedy token ids: exact on streams whose oracle top-2 margin exceeds the measured logit noise;
-    where a margin is inside the noise the argmax is not defined by the arithmetic and the test
-    reports it instead of failing.
+  * greedy token ids: EXACT, every step of every chunk, no waiver.  The weights are `decisive_state_dict` (random weights of
+    the real shapes + one planted copy head, weights.py), whose post-penalty top-2 margin is asserted on the oracle to be
+    >= 10x the logit noise measured in the same test -- with plain iid weights the top two of 152k logits are closer than
+    the bf16 noise of a 28-layer forward in a fixed share of the steps, whatever the kernels do;
+  * last-row logits of EVERY forward (the engine is teacher-forced with the oracle's tokens, so a flip cannot hide the
+    forwards behind it): both sides round to bf16 at the same ~12 points per layer and flash attention rounds
+    P = exp(s - running max) tile by tile, so any two valid tilings differ by single bf16 flips that propagate.
+    (a) absolute anchor: against the oracle run in fp32 ("truth": same weights, no rounding points) the HIP path may not be
+        further away than 1.25x what the bf16 oracle itself is, forward by forward (+1e-4 of the logit range);
+    (b) against the bf16 oracle: within 2.5x of the oracle's own re-tiling noise (global max vs 32-key tiles)
+        (mean|d|/max|ref| <= 2.5*floor + 5e-4, max <= 2.5*floor + 5e-3; DESIGN.md "Numerics").
 """
 import pytest
 import torch
@@ -20,79 +23,90 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _noise_floor(cfg, sd, n_chunks, ref, **kw):
-    """Logit error between two equally valid flash-attention tilings of the ORACLE itself (global max vs
-    32-key online tiles): the rounding noise any implementation of the reference numerics carries."""
+def _rel(a, b):
+    """(max, mean) of |a - b| over max|b|."""
+    d = (a - b).abs()
+    sc = float(b.abs().max())
+    return float(d.max()) / sc, float(d.mean()) / sc
+
+
+def _compare(cfg, sd, n_chunks, model, floor=True, truth=True, exact_tokens=True, **kw):
+    """`sd`: CPU state dict the model was built from.  Returns the measured numbers (printed as one [e2e] line)."""
     from oracle import model as om
-    om.ATTN_TILE = 32
-    try:
-        alt = H.run_oracle_stream(cfg, sd, n_chunks, keep_logits=True, **kw)
-    finally:
-        om.ATTN_TILE = None
-    fmax = fmean = 0.0
-    for i in range(n_chunks):
-        if alt["new_tokens"][i] != ref["new_tokens"][i]:
-            # histories diverge after this chunk; compare only what both computed from identical inputs
-            for a, b, ta, tb in zip(alt["logits"][i], ref["logits"][i], alt["new_tokens"][i], ref["new_tokens"][i]):
-                d = (a - b).abs(); sc = float(b.abs().max())
-                fmax, fmean = max(fmax, float(d.max()) / sc), max(fmean, float(d.mean()) / sc)
-                if ta != tb:
-                    break
-            break
-        for a, b in zip(alt["logits"][i], ref["logits"][i]):
-            d = (a - b).abs(); sc = float(b.abs().max())
-            fmax, fmean = max(fmax, float(d.max()) / sc), max(fmean, float(d.mean()) / sc)
-    return fmax, fmean
-
-
-def _compare(cfg, sd, n_chunks, model, **kw):
-    import streaming_vlm_amd as S  # noqa: F401
-    _, trace, counts, ids_log = H.run_engine_stream(model, n_chunks, keep_logits=True, **kw)
     ref = H.run_oracle_stream(cfg, sd, n_chunks, keep_logits=True, **kw)
-    floor_max, floor_mean = _noise_floor(cfg, sd, n_chunks, ref, **kw)
+    force = ref["generated"]
+    _, trace, counts, ids_log = H.run_engine_stream(model, n_chunks, keep_logits=True, force_tokens=force, **kw)
     assert trace == ref["trace"], f"eviction indices differ:\n{trace}\n{ref['trace']}"
-    worst_max = worst_mean = 0.0
-    diverged = False
     for i in range(n_chunks):
-        if diverged:
-            break
-        assert ids_log[i]["kv_len"] == ref["kv_len"][i]
-        for j, (a, b) in enumerate(zip(ids_log[i]["logits"], ref["logits"][i])):
-            scale = float(b.abs().max())
-            d = (a - b).abs()
-            worst_max = max(worst_max, float(d.max()) / scale)
-            worst_mean = max(worst_mean, float(d.mean()) / scale)
-            # the margin that decides the greedy token is the one AFTER the repetition penalty and the EOS suppression
-            # (streaming_generate_qwen.py:75-99): a seen token's logit is divided by 1.05, which can turn a clear raw margin
-            # into a near tie
-            from oracle import generate as og
-            n_new_i = len(ref["new_tokens"][i])
-            hist = ref["ids"][i][:len(ref["ids"][i]) - n_new_i + j]
-            sc = og.repetition_penalty(b.clone(), hist, 1.05)
-            if kw.get("suppress_eos", True):
-                sc[[151645, 151643]] = float("-inf")
-            top2 = torch.topk(sc, 2).values
-            margin = float(top2[0] - top2[1])
-            if ids_log[i]["new"][j] != ref["new_tokens"][i][j]:
-                noise = float(d.max())
-                print(f"[e2e] chunk {i} step {j}: token differs, oracle top-2 margin {margin:.3e} vs logit noise {noise:.3e}")
-                assert margin <= 4 * noise, "greedy token differs although the oracle margin is far above the noise"
-                diverged = True          # histories differ from here on; stop comparing
-                break
-    print(f"[e2e] logits: max rel err {worst_max:.3e}, mean rel err {worst_mean:.3e}; oracle-vs-oracle tiling noise floor "
-          f"max {floor_max:.3e} mean {floor_mean:.3e}; diverged={diverged}")
-    # the HIP path may not be further from the oracle than ~2x what the oracle is from itself under re-tiling
-    assert worst_mean <= 2.5 * floor_mean + 5e-4, (worst_mean, floor_mean)
-    assert worst_max <= 2.5 * floor_max + 5e-3, (worst_max, floor_max)
-    return diverged
+        assert ids_log[i]["kv_len"] == ref["kv_len"][i], (i, ids_log[i]["kv_len"], ref["kv_len"][i])
+        assert len(ids_log[i]["logits"]) == len(ref["logits"][i]) == len(force[i])
+    # ---- logits of every forward vs the bf16 oracle; absolute noise on the deciding logits
+    worst_max = worst_mean = noise_abs = 0.0
+    for i in range(n_chunks):
+        for a, b in zip(ids_log[i]["logits"], ref["logits"][i]):
+            mx, mn = _rel(a, b)
+            worst_max, worst_mean = max(worst_max, mx), max(worst_mean, mn)
+            noise_abs = max(noise_abs, float((a - b).abs().max()))
+    # ---- greedy tokens
+    margins = H.greedy_margins(ref, suppress_eos=kw.get("suppress_eos", True))
+    own = [e["own"] for e in ids_log]
+    n_steps = sum(len(f) for f in force)
+    n_same = sum(int(a == b) for o, f in zip(own, force) for a, b in zip(o, f))
+    if exact_tokens:
+        assert min(margins) >= 10 * noise_abs, f"weights are not decisive: min top-2 margin {min(margins):.3e} vs logit noise {noise_abs:.3e}"
+        assert own == force, f"greedy tokens differ: {n_same}/{n_steps} equal\n{own}\n{force}"
+    else:           # iid weights: a token may only differ where the oracle's own margin is inside 2x the measured noise
+        k = 0
+        for o, f in zip(own, force):
+            for a, b in zip(o, f):
+                assert a == b or margins[k] <= 2 * noise_abs, (k, a, b, margins[k], noise_abs)
+                k += 1
+    msg = (f"[e2e] {n_steps} forwards, tokens {n_same}/{n_steps} equal, min margin {min(margins):.3e} vs logit noise {noise_abs:.3e}; "
+           f"vs bf16 oracle: max rel {worst_max:.3e} mean rel {worst_mean:.3e}")
+    out = dict(worst_max=worst_max, worst_mean=worst_mean, noise_abs=noise_abs, min_margin=min(margins), same=n_same, steps=n_steps)
+    # ---- (a) fp32 truth
+    if truth:
+        sd32 = {k: v.float() for k, v in sd.items()}
+        tru = H.run_oracle_stream(cfg, sd32, n_chunks, keep_logits=True, force_tokens=force, **kw)
+        assert tru["trace"] == ref["trace"]
+        hip_sum = ora_sum = worst_ratio = 0.0
+        for i in range(n_chunks):
+            for a, b, t in zip(ids_log[i]["logits"], ref["logits"][i], tru["logits"][i]):
+                eh, eo = _rel(a, t)[1], _rel(b, t)[1]
+                hip_sum, ora_sum = hip_sum + eh, ora_sum + eo
+                worst_ratio = max(worst_ratio, eh / (eo + 1e-4))
+                assert eh <= 1.25 * eo + 1e-4, f"chunk {i}: HIP is {eh:.3e} from the fp32 truth, the bf16 oracle {eo:.3e}"
+        msg += (f"; vs fp32 truth: HIP mean rel {hip_sum / n_steps:.3e}, bf16 oracle {ora_sum / n_steps:.3e}, worst per-forward ratio "
+                f"{worst_ratio:.2f}, truth tokens {'==' if tru['own'] == force else '!='} oracle tokens")
+        out.update(hip_truth=hip_sum / n_steps, oracle_truth=ora_sum / n_steps, worst_ratio=worst_ratio)
+    # ---- (b) the oracle's own re-tiling noise
+    if floor:
+        om.ATTN_TILE = 32
+        try:
+            alt = H.run_oracle_stream(cfg, sd, n_chunks, keep_logits=True, force_tokens=force, **kw)
+        finally:
+            om.ATTN_TILE = None
+        fmax = fmean = 0.0
+        for i in range(n_chunks):
+            for a, b in zip(alt["logits"][i], ref["logits"][i]):
+                mx, mn = _rel(a, b)
+                fmax, fmean = max(fmax, mx), max(fmean, mn)
+        msg += f"; oracle re-tiling floor max {fmax:.3e} mean {fmean:.3e}"
+        print(msg)
+        assert worst_mean <= 2.5 * fmean + 5e-4, (worst_mean, fmean)
+        assert worst_max <= 2.5 * fmax + 5e-3, (worst_max, fmax)
+    else:
+        print(msg)
+    return out
 
 
-def _tiny_model(use_graph=True, family="qwen2", **kw):
+def _tiny_model(use_graph=True, family="qwen2", decisive=True, stream=None, **kw):
+    """`stream`: the kwargs of the stream the weights must be decisive for (frame size, tokens per chunk, all_text)."""
     import streaming_vlm_amd as S
     from streaming_vlm_amd import config as C
     from streaming_vlm_amd.weights import random_state_dict
     cfg = C.tiny_2_5(**kw) if family == "qwen2_5" else C.tiny(**kw)
-    sd = random_state_dict(cfg, 0, "cpu")
+    sd = H.decisive_weights(cfg, **(stream or {})) if decisive else random_state_dict(cfg, 0, "cpu")
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8, use_graph=use_graph)
     return cfg, sd, model
 
@@ -104,7 +118,7 @@ def test_tiny_stream_sink_window():
 
 def test_tiny_qwen2_5_stream_sink_window_ragged_windows():
     """Qwen2.5-VL family: windowed RMSNorm/SwiGLU tower (112x84 frames -> ragged attention windows), float temporal M-RoPE."""
-    cfg, sd, model = _tiny_model(family="qwen2_5")
+    cfg, sd, model = _tiny_model(family="qwen2_5", stream=dict(size=(112, 84)))
     _compare(cfg, sd, 6, model, size=(112, 84), window=96)
 
 
@@ -112,7 +126,7 @@ def test_tiny_qwen2_5_stream_structural_and_all_text():
     cfg, sd, model = _tiny_model(family="qwen2_5")
     _compare(cfg, sd, 7, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
              previous_text="a b c d e f g h i j k l m n o p")
-    cfg, sd, model = _tiny_model(family="qwen2_5")
+    cfg, sd, model = _tiny_model(family="qwen2_5", stream=dict(all_text=True))
     _compare(cfg, sd, 4, model, all_text=True)
 
 
@@ -124,6 +138,15 @@ def test_tiny_streams_append_mode():
                  previous_text="a b c d e f g h i j k l m n o p", pos_mode="append")
     cfg, sd, model = _tiny_model()
     _compare(cfg, sd, 6, model, pos_mode="append")
+
+
+def test_tiny_stream_iid_weights_teacher_forced():
+    """Plain N(0, 0.02) weights (no planted head): near-ties between the top two logits are part of the data, so the engine is
+    teacher-forced with the oracle's tokens and every forward's logits are held to the same bars; a token may differ only
+    where the oracle's own margin is inside twice the measured logit noise."""
+    cfg, sd, model = _tiny_model(decisive=False)
+    out = _compare(cfg, sd, 8, model, exact_tokens=False)
+    assert out["same"] >= 0.9 * out["steps"], out
 
 
 def test_tiny_stream_structural():
@@ -146,24 +169,58 @@ def test_graph_replay_equals_eager_launches():
 
 
 def test_golden_streams_eviction_trace_and_tokens():
-    """Committed oracle streams (tests/golden/oracle_streams.json, minted by oracle/make_golden.py) replayed on the HIP
-    engine with no oracle in the loop: eviction indices and KV lengths must be identical; greedy tokens are compared
-    chunk by chunk up to the first bf16-noise flip (histories differ from there on)."""
+    """Committed oracle streams (tests/golden/oracle_streams.json, minted in the build container by oracle/make_golden.py
+    with the decisive weights) replayed on the HIP engine with NO oracle in the loop: eviction indices, KV lengths and EVERY
+    greedy token of every chunk must be identical (cfg0: 32 chunks of 224x224, sink 4 / window 256)."""
     import json, os
     with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_streams.json")) as f:
         gold = json.load(f)
     for name, g in gold.items():
-        cfg, sd, model = _tiny_model(family="qwen2_5" if g.get("model") == "tiny_2_5" else "qwen2")
-        _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], **dict(g["kwargs"]))
+        kw = dict(g["kwargs"])
+        assert g["min_margin"] >= 0.5, (name, g["min_margin"])          # minted with decisive weights
+        cfg, sd, model = _tiny_model(family="qwen2_5" if g.get("model") == "tiny_2_5" else "qwen2",
+                                     stream=dict(size=kw.get("size", 56), all_text=kw.get("all_text", False)))
+        _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], **kw)
         assert [[list(t) for t in c] for c in trace] == g["trace"], name
         assert [e["kv_len"] for e in ids_log] == g["kv_len"], name
-        same = 0
-        for e, want in zip(ids_log, g["new_tokens"]):
-            if e["new"] != want:
-                break
-            same += 1
-        print(f"[golden] {name}: {same}/{g['n_chunks']} chunks token-identical before the first flip")
-        assert same >= 1, name
+        got = [e["new"] for e in ids_log]
+        same = sum(int(x == y) for x, y in zip(got, g["new_tokens"]))
+        print(f"[golden] {name}: {same}/{g['n_chunks']} chunks token-identical")
+        assert got == g["new_tokens"], (name, same)
+
+
+def test_golden_full_size_streams_tokens_exact():
+    """Full-size models against token streams minted by the CPU oracle in the build container (tests/golden/
+    full_size_streams.json): BASELINE configs[1] -- Qwen2-VL-2B, 448x448 @1 fps, sink 4 / window 2048, 20 tokens per chunk,
+    12 chunks so that the window is full and evicts -- and configs[2]'s model at its frame rate (Qwen2-VL-7B, 448x448
+    @2 fps, window 512 so that 3 chunks evict).  Every eviction index and every greedy token must be identical; the logit
+    behind each token must sit within 5 % of the oracle's margin of the oracle's value."""
+    import json, os
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    with open(os.path.join(os.path.dirname(__file__), "golden", "full_size_streams.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        kw = dict(g["kwargs"])
+        cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b}[g["model"]]()
+        sd = H.decisive_weights(cfg, size=kw["size"], max_new=kw["max_new"])
+        model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=g["max_len"], max_new_tokens=kw["max_new"])
+        del sd
+        _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], keep_logits=True, **kw)
+        assert [[list(t) for t in c] for c in trace] == g["trace"], name
+        assert [e["kv_len"] for e in ids_log] == g["kv_len"], name
+        got = [e["new"] for e in ids_log]
+        same = sum(int(x == y) for x, y in zip(got, g["new_tokens"]))
+        worst = 0.0
+        for e, tops, toks in zip(ids_log, g["top_logit"], g["new_tokens"]):
+            for lg, top, tok in zip(e["logits"], tops, toks):
+                worst = max(worst, abs(float(lg[tok]) - top))
+        print(f"[golden-full] {name}: {same}/{g['n_chunks']} chunks token-identical, kv_len max {max(g['kv_len'])}, "
+              f"|top logit - oracle| <= {worst:.3e}, oracle min margin {g['min_margin']:.3f}")
+        assert got == g["new_tokens"], (name, same)
+        assert worst <= 0.05 * g["min_margin"], (name, worst, g["min_margin"])
+        del model
+        torch.cuda.empty_cache()
 
 
 def test_vision_lookahead_is_bitwise_neutral():
@@ -217,23 +274,36 @@ def test_real_shape_2b_layer_stack_224():
     cfg = C.qwen2_vl_2b()
     cfg.vision.depth = 4
     cfg.text.num_layers = 4
-    sd = random_state_dict(cfg, 0, "cpu")
+    sd = H.decisive_weights(cfg, size=224)
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
     _compare(cfg, sd, 3, model, size=224, window=128)
 
 
 def test_full_size_2b_two_chunks_448():
     """BASELINE configs[1] at FULL size: Qwen2-VL-2B (28 LLM layers, 32 ViT blocks), 448x448 frames (1024 patches ->
-    256 vision tokens), 2 chunks x 8 tokens, sink 4 / window 256 so that the second chunk evicts.  Same bars as the
-    tiny model: identical eviction trace, logits within 2.5x of the oracle's own tiling noise."""
+    256 vision tokens), 2 chunks x 4 tokens, sink 4 / window 256 so that the second chunk evicts.  Same bars as the
+    tiny model: identical eviction trace, exact greedy tokens, logits anchored on the fp32 truth."""
     import streaming_vlm_amd as S
     from streaming_vlm_amd import config as C
     from streaming_vlm_amd.weights import random_state_dict
     torch.set_num_threads(min(16, torch.get_num_threads()))
     cfg = C.qwen2_vl_2b()
-    sd = random_state_dict(cfg, 0, "cpu")
+    sd = H.decisive_weights(cfg, size=448, max_new=4)
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
-    _compare(cfg, sd, 2, model, size=448, window=256, max_new=4)
+    _compare(cfg, sd, 2, model, floor=False, size=448, window=256, max_new=4)
+
+
+def test_full_size_7b_two_chunks_448():
+    """BASELINE configs[2]'s model at FULL size: Qwen2-VL-7B (28 layers of 3584 / 18944, 28 query / 4 kv heads, separate
+    lm_head), 448x448 frames at 2 fps (one 2-frame temporal patch per chunk), 2 chunks x 4 tokens, sink 4 / window 256 so that
+    the second chunk evicts.  Same bars: identical eviction trace, exact greedy tokens, logits anchored on the fp32 truth."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = C.qwen2_vl_7b()
+    sd = H.decisive_weights(cfg, size=448, max_new=4)
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
+    _compare(cfg, sd, 2, model, floor=False, size=448, fps=2.0, window=256, max_new=4)
 
 
 def test_full_size_qwen2_5_vl_3b_two_chunks_448():
@@ -244,9 +314,9 @@ def test_full_size_qwen2_5_vl_3b_two_chunks_448():
     from streaming_vlm_amd.weights import random_state_dict
     torch.set_num_threads(min(16, torch.get_num_threads()))
     cfg = C.qwen2_5_vl_3b()
-    sd = random_state_dict(cfg, 0, "cpu")
+    sd = H.decisive_weights(cfg, size=448, max_new=4)
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
-    _compare(cfg, sd, 2, model, size=448, window=256, max_new=4)
+    _compare(cfg, sd, 2, model, floor=False, size=448, window=256, max_new=4)
 
 
 def test_tight_pool_defragments_in_place_and_stays_exact():
@@ -256,7 +326,7 @@ def test_tight_pool_defragments_in_place_and_stays_exact():
     from streaming_vlm_amd import config as C
     from streaming_vlm_amd.weights import random_state_dict
     cfg = C.tiny()
-    sd = random_state_dict(cfg, 0, "cpu")
+    sd = H.decisive_weights(cfg)
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=200, max_new_tokens=8, kv_slack=0.05,
                                kv_page_tokens=16)
     _compare(cfg, sd, 12, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
@@ -302,7 +372,7 @@ def test_tiny_stream_with_the_7b_head_grouping():
     from streaming_vlm_amd.weights import random_state_dict
     cfg = C.tiny()
     cfg.text.num_heads, cfg.text.num_kv_heads = 7, 1
-    sd = random_state_dict(cfg, 0, "cpu")
+    sd = H.decisive_weights(cfg)
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8)
     _compare(cfg, sd, 5, model)
 

@@ -30,12 +30,13 @@ def test_engine_equals_oracle_and_golden_traces(tiny, golden_dir):
     with open(os.path.join(golden_dir, "oracle_streams.json")) as f:
         gold = json.load(f)
     cfg25 = C.tiny_2_5()
-    sd25 = random_state_dict(cfg25, 0, "cpu")
     for name, g in gold.items():
         if "default" in name:
             continue
         kw = dict(g["kwargs"])
-        model = _model(cfg25, sd25) if g.get("model") == "tiny_2_5" else _model(cfg, sd)       # Qwen2.5-VL family streams
+        # the streams were minted on the decisive weights of their geometry (oracle/make_golden.py)
+        c = cfg25 if g.get("model") == "tiny_2_5" else cfg                                     # Qwen2.5-VL family streams
+        model = _model(c, H.decisive_weights(c, size=kw.get("size", 56), all_text=kw.get("all_text", False)))
         res, trace, counts, log = H.run_engine_stream(model, g["n_chunks"], **kw)
         assert [[list(t) for t in c] for c in trace] == g["trace"], name          # identical eviction indices
         assert [e["kv_len"] for e in log] == g["kv_len"], name
@@ -48,8 +49,9 @@ def test_default_structural_policy_trace(tiny, golden_dir):
     cfg, sd = tiny
     with open(os.path.join(golden_dir, "oracle_streams.json")) as f:
         g = json.load(f)["structural_default_16"]
-    res, trace, counts, log = H.run_engine_stream(_model(cfg, sd), g["n_chunks"], **g["kwargs"])
+    res, trace, counts, log = H.run_engine_stream(_model(cfg, H.decisive_weights(cfg)), g["n_chunks"], **g["kwargs"])
     assert [[list(t) for t in c] for c in trace] == g["trace"]
+    assert [e["new"] for e in log] == g["new_tokens"]
     assert any(len(c) for c in trace), "20 chunks must trigger the 16-round eviction"
 
 
@@ -274,8 +276,12 @@ def test_cli_mirrors_the_reference_flags(tiny, tmp_path, monkeypatch, capsys):
     """`python -m streaming_vlm_amd.driver` takes the reference's flags (inference.py:524-561), writes WebVTT and JSON lines."""
     from streaming_vlm_amd import driver as drv
     cfg, sd = tiny
-    big = S.StreamingQwen2VL(cfg, sd, "cpu", ops=RefOps(), max_len=1024, max_new_tokens=20, use_graph=False)
-    monkeypatch.setattr(drv, "load_model_and_processor", lambda path, base: (big, S.SyntheticProcessor()))
+    built = []
+
+    def load(path, base, max_len=None, max_new_tokens=None):          # the CLI's own sizing, on the CPU test backend
+        built.append(max_len)
+        return S.StreamingQwen2VL(cfg, sd, "cpu", ops=RefOps(), max_len=max_len, max_new_tokens=max_new_tokens, use_graph=False), S.SyntheticProcessor()
+    monkeypatch.setattr(drv, "load_model_and_processor", load)
     vtt = tmp_path / "out.vtt"
     out = drv._cli(["--model_path", "random:tiny", "--model_base", "Qwen2", "--video_path", "synthetic://56x56@1fps", "--duration", "2",
                     "--window_size", "4", "--text_round", "4", "--output_dir", str(vtt), "--emit_json", "--quiet", "--greedy"])
@@ -284,3 +290,27 @@ def test_cli_mirrors_the_reference_flags(tiny, tmp_path, monkeypatch, capsys):
     assert [l["start"] for l in lines] == [0.0, 1.0] and all(l["type"] == "segment" for l in lines)
     text = vtt.read_text()
     assert text.startswith("WEBVTT\n\n00:00:00.000 --> 00:00:01.000\n") and "00:00:01.000 --> 00:00:02.000" in text
+    # the reference's DEFAULT settings (16 vision rounds, 16 text rounds, 512 + 512 previous text, 20 tokens per chunk) past the
+    # first structural eviction: the engine the CLI sizes for itself must hold the whole stream
+    out = drv._cli(["--model_path", "random:tiny", "--model_base", "Qwen2", "--video_path", "synthetic://56x56@1fps", "--duration", "19",
+                    "--output_dir", str(tmp_path / "d.vtt"), "--quiet", "--greedy"])
+    assert len(out) == 19 and built[-1] is not None and built[-1] < 4096, built
+
+
+def test_required_max_len_bounds_every_golden_stream(golden_dir):
+    """The engine capacity `streaming_inference` derives from the eviction policy (driver.required_max_len) must cover the longest
+    sequence each committed stream reaches (cached rows + un-cached suffix + generated tokens), and stay within 2x of it."""
+    from streaming_vlm_amd.driver import required_max_len
+    with open(os.path.join(golden_dir, "oracle_streams.json")) as f:
+        gold = json.load(f)
+    for name, g in gold.items():
+        kw = dict(g["kwargs"])
+        size = kw.get("size", 56)
+        h, w = (size, size) if isinstance(size, int) else size
+        n_tok = (h // 28) * (w // 28)
+        prev = kw.get("previous_text", "hello world")
+        need = required_max_len(n_tok, 8, kw["policy"], kw.get("window_size", 16), kw.get("text_round", 16), kw.get("text_sink"),
+                                kw.get("text_sliding_window"), kw.get("sink", 4), kw.get("window", 64), g["n_chunks"], len(prev.split()))
+        longest = max(g["kv_len"]) + 2
+        assert longest <= need, (name, longest, need)
+        assert need <= 2 * longest + 64, (name, longest, need)
