@@ -314,3 +314,31 @@ def test_required_max_len_bounds_every_golden_stream(golden_dir):
         longest = max(g["kv_len"]) + 2
         assert longest <= need, (name, longest, need)
         assert need <= 2 * longest + 64, (name, longest, need)
+
+
+def test_efficiency_harness_emits_the_reference_document(tiny, tmp_path):
+    """tools/efficiency_modes.py: the four modes of eval/efficiency/efficiency_test.py on the CPU test backend; the saved
+    document carries the reference's keys (efficiency_test.py:87-136) and mode (b) shows its saw-tooth once the stream is
+    longer than its window (here a 6-chunk window so that the CPU run stays short)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("efficiency_modes", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "efficiency_modes.py"))
+    em = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(em)
+    cfg, sd = tiny
+    for mode, over, chunks in (("a", {}, 6), ("b", dict(window_size=6, text_round=6), 16), ("c", dict(window_size=3, text_round=3), 6), ("d", {}, 6)):
+        mcfg = dict(em.MODES[mode], **over)
+        model = S.StreamingQwen2VL(cfg, sd, "cpu", ops=RefOps(), max_len=em.mode_max_len(mcfg, chunks, 4), max_new_tokens=20, use_graph=False)
+        p = em.efficiency_payload(mode, model, S.SyntheticProcessor(), None, chunks, model_path="random:tiny", video_path="synthetic://56x56@1fps", **over)
+        assert set(p) >= {"meta", "per_chunk", "summary"}
+        assert set(p["meta"]) == {"timestamp", "model_path", "model_base", "video_path", "pos_mode", "all_text", "skip_first_chunk", "temperature",
+                                  "mode", "window_size", "chunk_duration", "text_round", "text_sink", "text_sliding_window", "recompute",
+                                  "duration_tested_sec"}
+        assert p["meta"]["mode"] == em.MODE_NAMES[mode] and p["meta"]["recompute"] == (mode == "c")
+        assert len(p["per_chunk"]) == chunks == p["summary"]["num_chunks"]
+        assert set(p["per_chunk"][0]) == {"chunk_index", "time_start_sec", "video_len_sec", "gen_time_sec", "decoded_tokens", "gen_time_per_token"}
+        assert all(r["decoded_tokens"] == 20 and r["gen_time_per_token"] > 0 for r in p["per_chunk"])
+        assert p["summary"]["avg_gen_time_per_token"] > 0
+        path = em.save_payload(p, str(tmp_path))
+        assert os.path.basename(path).startswith(em.MODE_NAMES[mode] + "__Qwen2__random:tiny__") and json.load(open(path))["meta"] == p["meta"]
+        if mode == "b":          # the KV cache stops growing once the 6-chunk window is full
+            assert p["svlm"]["kv_len_last"] < 16 * 40
