@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--ingest", default="resident", choices=["resident", "host"],
                     help="resident: patches already in HBM when the timed region starts (the contract's `value`); host: uint8 frames in "
                          "pinned host memory, H2D + GPU patchify inside the timed region (the PCIe-inclusive rate, DESIGN.md section 6)")
+    ap.add_argument("--sampling", default="greedy", choices=["greedy", "temperature", "hf-default"],
+                    help="token choice: greedy (the contract's line, BASELINE configs); temperature = the reference's call (do_sample, T 0.9, "
+                         "Gumbel-max in the captured graph); hf-default = the same with HF's default top_k 50 (the filter kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -125,7 +128,8 @@ def main():
 
     S.streaming_inference(model=model, processor=proc, video=video, model_base="Qwen2_5" if cfg.family == "qwen2_5" else "Qwen2",
                           duration=n_chunks, previous_text="",
-                          kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=False,
+                          kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=args.sampling != "greedy",
+                          temperature=0.9, top_k={"greedy": None, "temperature": 0, "hf-default": 50}[args.sampling], top_p=1.0,
                           max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk,
                           ids_log=kvlog)
     fence()
@@ -146,7 +150,7 @@ def main():
         "ms_per_step": round(1e3 * t_max / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic" if args.ingest == "resident" else "synthetic uint8 frames from pinned host memory (PCIe-inclusive)",
         "config": {"workload": f"{cfg.name} bf16, {args.size}x{args.size} @{args.fps:g}fps synthetic stream, KV sink={args.sink} "
-                               f"window={args.window}, {args.new_tokens} greedy tokens/chunk, one stream per GPU",
+                               f"window={args.window}, {args.new_tokens} {'greedy' if args.sampling == 'greedy' else 'sampled (' + args.sampling + ')'} tokens/chunk, one stream per GPU",
                    "frames_per_chunk": frames_per_chunk, "new_tokens_per_chunk": args.new_tokens, "kv_len_steady": kv_steady[0],
                    "kv_fill_chunks": fill, "vit_passes_in_timed_region": args.steps, "parallelism": f"streams{world}"},
         "per_gpu_frames_per_sec": [round(v, 3) for v in per_gpu_fps],

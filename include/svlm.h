@@ -157,6 +157,17 @@ long long svlm_argmax_ws_bytes(void);
 int svlm_penalty_argmax(const float* logits, int V, void* seen, float penalty, const int* suppress, int n_suppress, int* tok_buf,
                         int* state, int advance_kv, void* ws, void* stream);
 
+/* The reference's DEFAULT token choice (do_sample=True at inference.py:446; generate/streaming_generate_qwen.py:75,95-97 with the
+ * warpers HF builds from the generation config): repetition penalty -> temperature -> top-k (0 = off; every score >= the k-th
+ * largest survives) -> top-p (1 = off) -> softmax -> one multinomial draw, then the same device-side token feedback as
+ * svlm_penalty_argmax.  rng = {seed lo, seed hi} in DEVICE memory (Philox4x32-10, counted by the generated-token index
+ * state[1]+1 and the vocabulary index); top_k == 1 is the argmax; top_k == 0 && top_p == 1 is a Gumbel-max draw inside the
+ * argmax kernels; 1 < top_k < 2048 runs one single-workgroup select / sort / cut / inverse-CDF kernel; top_p alone (or a wider
+ * k) runs the threshold form -- radix descent by count and by probability mass, then a Gumbel-max over the survivors -- which is
+ * exact for a nucleus of any size.  ws >= svlm_argmax_ws_bytes(). */
+int svlm_penalty_sample(const float* logits, int V, void* seen, float penalty, const int* suppress, int n_suppress, float temperature,
+                        int top_k, float top_p, const unsigned* rng, int* tok_buf, int* state, int advance_kv, void* ws, void* stream);
+
 /* ---- fused decode-step (T = 1) kernels: the per-layer small ops folded into the weight-streaming GEMVs ---- */
 /* RMSNorm(x; ln_w) -> W x + bias -> q_out (qd) and the new token's K/V rows written straight into the pool slot
  * slot_of[*len_dev or len_host].  replaces: qwen2/language_forward.py:183,80-82 + generate/streaming_cache.py:72-73. */
@@ -173,6 +184,12 @@ long long svlm_dec_lm_head_ws_bytes(int V);
 int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen, float penalty,
                      const int* suppress, int n_suppress, void* ws, int V, int K, void* stream);
 int svlm_argmax_finish(const void* ws, int V, void* seen, int* tok_buf, int* state, int advance_kv, void* stream);
+/* svlm_dec_lm_head with plain temperature sampling folded in: the candidates are argmax(score / T + Gumbel noise), an exact
+ * draw from softmax(score / T); rng / state as svlm_penalty_sample.  svlm_argmax_finish completes it.
+ * replaces: generate/streaming_generate_qwen.py:95-97 (softmax + torch.multinomial) on decode steps. */
+int svlm_dec_lm_head_sample(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen,
+                            float penalty, const int* suppress, int n_suppress, void* ws, int V, int K, float temperature,
+                            const unsigned* rng, const int* state, void* stream);
 
 #ifdef __cplusplus
 }

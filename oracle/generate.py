@@ -35,6 +35,28 @@ def repetition_penalty(logits_f32: torch.Tensor, ids, penalty: float):
     return logits_f32
 
 
+def warp_scores(scores: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0) -> torch.Tensor:
+    """The warpers HF's generate() appends to the processor list under do_sample=True, in its order (transformers
+    generation/utils.py _get_logits_processor; generation/logits_process.py): TemperatureLogitsWarper (scores / T),
+    TopKLogitsWarper (everything below the k-th largest score -> -inf; ties at the threshold survive), TopPLogitsWarper
+    (sort ascending, softmax, cumulative sum; tokens whose cumulative probability is <= 1 - top_p -> -inf, the largest always
+    survives).  The reference reaches them through `logits_processor(input_ids, next_token_logits)`,
+    generate/streaming_generate_qwen.py:75."""
+    sc = scores.clone()
+    if temperature != 1.0:
+        sc = sc / temperature
+    if top_k and top_k > 0:
+        k = min(int(top_k), sc.numel())
+        sc = sc.masked_fill(sc < torch.topk(sc, k).values[-1], float("-inf"))
+    if top_p < 1.0:
+        sorted_sc, sorted_idx = torch.sort(sc, descending=False)
+        cum = sorted_sc.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[-1:] = False
+        sc = sc.masked_fill(torch.zeros_like(remove).scatter(0, sorted_idx, remove), float("-inf"))
+    return sc
+
+
 @dataclass
 class GenOut:
     sequences: List[int]
@@ -46,7 +68,7 @@ class GenOut:
 
 def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=None, grid_thw=None,
              max_new_tokens=20, rep_penalty=1.05, eos_ids=(151645, 151643), suppress_eos=False,
-             do_sample=False, temperature=1.0, generator: Optional[torch.Generator] = None,
+             do_sample=False, temperature=1.0, top_k: int = 0, top_p: float = 1.0, generator: Optional[torch.Generator] = None,
              keep_logits=False, all_text=False, second_per_grid_t=1.0, pos_mode="shrink", sargs: Optional[dict] = None,
              force_tokens: Optional[List[int]] = None) -> GenOut:
     """One ``model.generate(**inputs, past_key_values=kv, streaming_args=...)`` call.  `sargs` is the part of StreamingArgs
@@ -99,8 +121,8 @@ def generate(w, cfg: ModelCfg, ids: List[int], kv, video_grid_thw, pixel_values=
         if suppress_eos:
             sc = sc.clone()
             sc[list(eos_ids)] = float("-inf")
-        if do_sample:
-            probs = torch.softmax(sc / temperature, dim=-1)
+        if do_sample:                                                       # :92-97
+            probs = torch.softmax(warp_scores(sc, temperature, top_k, top_p), dim=-1)
             nxt = int(torch.multinomial(probs, 1, generator=generator))
         else:
             nxt = int(torch.argmax(sc))                                     # :99

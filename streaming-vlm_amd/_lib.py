@@ -52,6 +52,8 @@ SIGNATURES = {
     "svlm_mark_seen": (_i, [_p, _i, _p, _i, _p]),
     "svlm_argmax_ws_bytes": (_ll, []),
     "svlm_penalty_argmax": (_i, [_p, _i, _p, _f, _p, _i, _p, _p, _i, _p, _p]),
+    "svlm_penalty_sample": (_i, [_p, _i, _p, _f, _p, _i, _f, _i, _f, _p, _p, _p, _i, _p, _p]),
+    "svlm_dec_lm_head_sample": (_i, [_p, _p, _f, _p, _i, _p, _p, _f, _p, _i, _p, _i, _i, _f, _p, _p, _p]),
     "svlm_dec_qkv": (_i, [_p, _p, _f, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "svlm_dec_gate_up": (_i, [_p, _p, _f, _p, _i, _p, _i, _i, _p]),
     "svlm_dec_lm_head_ws_bytes": (_ll, [_i]),

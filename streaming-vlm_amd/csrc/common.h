@@ -124,6 +124,35 @@ __device__ __forceinline__ float apply_act(float y, int act) {
   return y;
 }
 
+// ---- Philox4x32-10 (Salmon et al., SC'11): counter-based, no state to carry between launches
+__device__ __forceinline__ unsigned svlm_philox_first(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
+  unsigned c2 = 0u, c3 = 0u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+// uniform in (0, 1): 23 random bits + 1/2, exactly representable in fp32, never 0 or 1
+__device__ __forceinline__ float svlm_philox_uniform(const unsigned* __restrict__ rng, unsigned step, unsigned idx) {
+  return ((float)(svlm_philox_first(idx, step, rng[0], rng[1]) >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+// standard Gumbel noise g = -log(E), E ~ Exp(1).  The draw that WINS an argmax over a vocabulary of ~1.5e5 sits in the upper tail
+// (g ~ 12, E ~ 6e-6): E = -log1p(-v) with v = (x + 1/2) * 2^-32 keeps all 32 random bits where E is small (v is exact in fp32 for
+// x < 2^24), so that tail is resolved to ~1e-10 instead of the 6e-8 steps of a 24-bit uniform; v = 1 (x rounds up to 2^32,
+// probability 2^-25) gives g = -inf, a token that simply does not win.
+__device__ __forceinline__ float svlm_gumbel_noise(const unsigned* __restrict__ rng, unsigned step, unsigned idx) {
+  const float v = ((float)svlm_philox_first(idx, step, rng[0], rng[1]) + 0.5f) * (1.0f / 4294967296.0f);
+  return -logf(-log1pf(-v));
+}
+
 void svlm_set_error(const char* fmt, ...);
 #define SVLM_CHECK_ARG(cond, ...)                    \
   do {                                               \

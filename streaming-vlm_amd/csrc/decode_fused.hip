@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ W, int ldw, float* __restrict__ logits,
                                                           const unsigned char* __restrict__ seen, float penalty,
                                                           const int* __restrict__ suppress, int n_suppress,
-                                                          float* __restrict__ part_val, int* __restrict__ part_idx, int V, int K) {
+                                                          float* __restrict__ part_val, int* __restrict__ part_idx, int V, int K,
+                                                          float inv_temp, const unsigned* __restrict__ rng,
+                                                          const int* __restrict__ state) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + wave) * ROWS;
@@ -242,6 +244,8 @@ __global__ __launch_bounds__(256) void dec_lm_head_kernel(const bf16_t* __restri
       if (seen && seen[n]) v = v < 0.f ? v * penalty : v / penalty;
       for (int s = 0; s < n_suppress; ++s)
         if (suppress[s] == n) v = -INFINITY;
+      // temperature sampling = Gumbel-max over the processed scores (sampling.hip); every lane draws the same noise
+      if (rng) v = v * inv_temp + svlm_gumbel_noise(rng, (unsigned)(state[1] + 1), (unsigned)n);
       if (v > best || (v == best && n < bi)) { best = v; bi = n; }
     }
   }
@@ -326,8 +330,9 @@ extern "C" int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, cons
 #define LM_ROWS 4
 extern "C" long long svlm_dec_lm_head_ws_bytes(int V) { return V <= 0 ? SVLM_EINVAL : (long long)((V + 4 * LM_ROWS - 1) / (4 * LM_ROWS)) * 8; }
 
-extern "C" int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen,
-                                float penalty, const int* suppress, int n_suppress, void* ws, int V, int K, void* stream) {
+static int dec_lm_head_launch(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen,
+                              float penalty, const int* suppress, int n_suppress, void* ws, int V, int K, float inv_temp,
+                              const unsigned* rng, const int* state, void* stream) {
   SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0 && V > 0, "svlm_dec_lm_head: bad V=%d K=%d ldw=%d", V, K, ldw);
   SVLM_CHECK_ARG(penalty > 0.f && n_suppress >= 0 && n_suppress <= 8 && ws != nullptr && logits != nullptr, "svlm_dec_lm_head: bad sampling args");
   const int nb = (V + 4 * LM_ROWS - 1) / (4 * LM_ROWS);
@@ -335,8 +340,22 @@ extern "C" int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, cons
   int* pi = (int*)(pv + nb);
   DEC_DISPATCH(dec_lm_head_kernel, LM_ROWS, K, <<<nb, 256, K * 2, (hipStream_t)stream>>>(
       (const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, logits, (const unsigned char*)seen, penalty, suppress,
-      n_suppress, pv, pi, V, K));
+      n_suppress, pv, pi, V, K, inv_temp, rng, state));
   return svlm_check_launch("svlm_dec_lm_head");
+}
+
+extern "C" int svlm_dec_lm_head(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen,
+                                float penalty, const int* suppress, int n_suppress, void* ws, int V, int K, void* stream) {
+  return dec_lm_head_launch(x, ln_w, eps, W, ldw, logits, seen, penalty, suppress, n_suppress, ws, V, K, 1.0f, nullptr, nullptr, stream);
+}
+
+// The same launch with temperature sampling folded in: the candidates are argmax(score / T + Gumbel noise), an exact draw from
+// softmax(score / T) (sampling.hip); rng = {seed lo, seed hi} and state = {kv_len, cur} live in device memory.
+extern "C" int svlm_dec_lm_head_sample(const void* x, const void* ln_w, float eps, const void* W, int ldw, float* logits, const void* seen,
+                                       float penalty, const int* suppress, int n_suppress, void* ws, int V, int K, float temperature,
+                                       const unsigned* rng, const int* state, void* stream) {
+  SVLM_CHECK_ARG(temperature > 0.f && rng != nullptr && state != nullptr, "svlm_dec_lm_head_sample: bad temperature=%f / null rng or state", temperature);
+  return dec_lm_head_launch(x, ln_w, eps, W, ldw, logits, seen, penalty, suppress, n_suppress, ws, V, K, 1.0f / temperature, rng, state, stream);
 }
 
 extern "C" int svlm_argmax_finish(const void* ws, int V, void* seen, int* tok_buf, int* state, int advance_kv, void* stream) {

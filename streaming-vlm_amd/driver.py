@@ -237,7 +237,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
                         generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True, force_tokens=None,
-                        max_len=None):
+                        max_len=None, top_k=None, top_p=None):
     # The reference synchronises the device around every section to print per-section times.  Nobody reads them when the
     # loop is quiet and not under time_test, and each of the dozen syncs per chunk is host time the GPU spends idle.
     timed_sections = time_test or not quiet
@@ -409,6 +409,10 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                       temperature=temperature, suppress_eos=suppress_eos, generator=generator, keep_logits=keep_logits)
         if lookahead is not None:
             gen_kw["next_vision"] = (lookahead[1], lookahead[2])
+        if top_k is not None:                 # None: the model's generation_config / HF defaults (model.py)
+            gen_kw["top_k"] = top_k
+        if top_p is not None:
+            gen_kw["top_p"] = top_p
         if force_tokens is not None:          # parity tests: per-chunk teacher forcing (engine.generate)
             gen_kw["force_tokens"] = force_tokens[i]
         if recompute:

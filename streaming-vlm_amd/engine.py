@@ -246,6 +246,12 @@ class SvlmEngine:
         self._graph_key = None
         self._penalty = 1.0
         self._suppress = None
+        # token choice: None = greedy, else (temperature, top_k, top_p); HF GenerationConfig's own defaults for a model that does not
+        # say otherwise (convert_* reads the checkpoint's generation_config, model.py)
+        self._sampling = None
+        self.default_top_k, self.default_top_p = 50, 1.0
+        self.rng_dev = torch.zeros(2, dtype=torch.int32, device=dev)       # Philox seed of the current generate() call
+        self._sample_calls = 0
 
     @staticmethod
     def pick_decode_chunk(max_len: int, n_kv_heads: int) -> int:
@@ -421,12 +427,23 @@ class SvlmEngine:
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
             o.dec_gate_up(self.d_x, lw["ln2"], tc.rms_eps, lw["gu_w"], self.d_h)
             o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)
-        o.dec_lm_head(self.d_x, w.final_norm, tc.rms_eps, w.lm_head, self.logits, self.seen if self._penalty != 1.0 else None,
-                      self._penalty, self._suppress, self.d_sws)
+        smp = self._sampling
+        if smp is not None and smp[1] == 0 and smp[2] >= 1.0:     # plain temperature sampling: Gumbel-max inside the candidates
+            o.dec_lm_head(self.d_x, w.final_norm, tc.rms_eps, w.lm_head, self.logits, self.seen if self._penalty != 1.0 else None,
+                          self._penalty, self._suppress, self.d_sws, temperature=smp[0], rng=self.rng_dev, state=self.state)
+        else:
+            o.dec_lm_head(self.d_x, w.final_norm, tc.rms_eps, w.lm_head, self.logits, self.seen if self._penalty != 1.0 else None,
+                          self._penalty, self._suppress, self.d_sws)
 
     def _sample_launch(self, advance_kv: int, fused: bool = False):
+        """Token choice + device-side feedback (tok_buf / state / seen).  `fused`: dec_lm_head already left its candidates in
+        d_sws (greedy, or Gumbel-max sampling); top-k / top-p draws always go through the filter kernel on the logits row."""
         seen = self.seen if self._penalty != 1.0 else None
-        if fused:      # candidates already left in d_sws by dec_lm_head
+        smp = self._sampling
+        if smp is not None and not (smp[1] == 0 and smp[2] >= 1.0 and fused):
+            self.ops.penalty_sample(self.logits, seen, self._penalty, self._suppress, smp[0], smp[1], smp[2], self.rng_dev, self.tok_buf,
+                                    self.state, advance_kv, self.d_sws)
+        elif fused:      # candidates already left in d_sws by dec_lm_head
             self.ops.argmax_finish(self.d_sws, self.cfg.text.vocab_size, seen, self.tok_buf, self.state, advance_kv)
         else:
             self.ops.penalty_argmax(self.logits, seen, self._penalty, self._suppress, self.tok_buf, self.state, advance_kv, self.d_sws)
@@ -436,7 +453,7 @@ class SvlmEngine:
             self._decode_step_launch(c)
             self._sample_launch(1, fused=True)
             return
-        key = (id(c), self._penalty, self._suppress is not None)
+        key = (id(c), self._penalty, self._suppress is not None, self._sampling)
         if self._graph is None or self._graph_key != key:
             # capture once per (cache, sampling config); state is restored because capture does not execute
             g = torch.cuda.CUDAGraph()
@@ -451,7 +468,8 @@ class SvlmEngine:
                  max_new_tokens: int = 20, repetition_penalty: float = 1.05, do_sample: bool = False, temperature: float = 1.0,
                  suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
                  all_text: bool = False, second_per_grid_t: Optional[float] = None, pos_mode: str = "shrink",
-                 last_cache_position: float = -1, force_tokens: Optional[Sequence[int]] = None) -> GenerateOutput:
+                 last_cache_position: float = -1, force_tokens: Optional[Sequence[int]] = None, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None) -> GenerateOutput:
         """`next_vision=(pixel_values, grid_thw)` of the FOLLOWING chunk, when the caller already has its frames, is
         encoded on a side stream underneath this chunk's decode steps (see `vision_prefetch`).
         `force_tokens` (greedy only): teacher forcing for parity tests -- every step still takes its own argmax on the device
@@ -537,14 +555,30 @@ class SvlmEngine:
             o.mark_seen(self.ids_dev, L_ids, self.seen)
         self.state.copy_(torch.tensor([L_ids, -1], dtype=torch.int32))
         logits_out = [] if keep_logits else None
+        # ---- token choice (streaming_generate_qwen.py:75-99): greedy, or HF's warpers + one multinomial draw per token, on the device
+        self._sampling = None
+        if do_sample:
+            if force_tokens is not None:
+                raise ValueError("force_tokens is a greedy-parity aid; it cannot be combined with do_sample")
+            k = self.default_top_k if top_k is None else int(top_k)
+            p = self.default_top_p if top_p is None else float(top_p)
+            if temperature <= 0 or k < 0 or not (0.0 < p <= 1.0):
+                raise ValueError(f"bad sampling settings: temperature={temperature} top_k={k} top_p={p}")
+            if k != 1:                                   # top_k = 1 leaves one survivor: the argmax
+                self._sampling = (float(temperature), k, p)
+                # one Philox seed per call: the caller's generator seed (or 42, the reference's set_seed, inference.py:24-25)
+                # mixed with the call count -- no device round trip, reproducible per engine instance
+                base = (generator.initial_seed() if generator is not None else 42) & 0xFFFFFFFFFFFFFFFF
+                z = (base + 0x9E3779B97F4A7C15 * (self._sample_calls + 1)) & 0xFFFFFFFFFFFFFFFF
+                z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+                z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+                z ^= z >> 31
+                self._sample_calls += 1
+                self.rng_dev.copy_(torch.from_numpy(np.array([z & 0xFFFFFFFF, z >> 32], dtype=np.uint32).view(np.int32)))
 
         self._prefill(cache, idx_dev, vis, T, L_before)
         if keep_logits:
             logits_out.append(self.logits.detach().cpu().clone())
-        if do_sample:
-            if next_vision is not None:
-                self.vision_prefetch(*next_vision)
-            return self._generate_sampling(ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out, L_before, pos_full)
         self._sample_launch(0)
         own = None
         if force_tokens is not None:
@@ -594,33 +628,3 @@ class SvlmEngine:
                     self.seen[mine] = 0
                 self.seen[tok] = 1
         seen_host.add(tok)
-
-    def _generate_sampling(self, ids, cache, L_ids, max_new_tokens, temperature, generator, logits_out, L_before, pos_full):
-        """do_sample=True (the reference's default: T=0.9, multinomial, streaming_generate_qwen.py:95-97).
-        Token choice runs through torch on the device (RNG plumbing); forwards are the same kernels."""
-        cfg = self.cfg
-        new = []
-        seen_ids = torch.from_numpy(np.unique(ids)).to(self.device)
-        for step in range(max_new_tokens):
-            sc = self.logits.clone()
-            if self._penalty != 1.0:
-                s = sc[seen_ids]
-                sc[seen_ids] = torch.where(s < 0, s * self._penalty, s / self._penalty)
-            if self._suppress is not None:
-                sc[self._suppress.long()] = float("-inf")
-            probs = torch.softmax(sc / temperature, dim=-1)
-            tok = int(torch.multinomial(probs, 1, generator=generator))
-            new.append(tok)
-            seen_ids = torch.cat([seen_ids, torch.tensor([tok], device=self.device)])
-            if tok in cfg.eos_token_ids or step + 1 >= max_new_tokens:
-                break
-            self.tok_buf[step:step + 1].copy_(torch.tensor([tok], dtype=torch.int32))
-            self.state.copy_(torch.tensor([L_ids + step, step], dtype=torch.int32))
-            self._decode_step_launch(cache)
-            if logits_out is not None:
-                logits_out.append(self.logits.detach().cpu().clone())
-        cache.commit(L_ids + len(new) - 1)
-        cache.release_reserved()
-        cache.pos_rows[:, L_before:cache.length] = pos_full[:, L_before:cache.length]
-        self.last_position = float(pos_full[0, cache.length - 1])
-        return GenerateOutput(ids.tolist() + new, cache, logits_out, len(new))

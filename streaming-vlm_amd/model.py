@@ -40,7 +40,7 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
                        return_dict_in_generate: bool = True, do_sample: bool = True, repetition_penalty: float = 1.0,
                        streaming_args: Optional[StreamingArgs] = None, pad_token_id=None, temperature: float = 1.0,
                        second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
-                       force_tokens=None, **unused):
+                       force_tokens=None, top_k=None, top_p=None, **unused):
     """Greedy / sampling generation on the HIP engine (reference: streaming_generate + _sample,
     generate/streaming_generate_qwen.py:130-278, 8-127)."""
     eng: SvlmEngine = self._svlm_engine
@@ -59,7 +59,7 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
     out = eng.generate(ids, past_key_values, grids_all, pixel_values_videos, _grid_list(video_grid_thw), max_new_tokens,
                        repetition_penalty, do_sample, temperature, suppress_eos, keep_logits, generator, next_vision,
                        all_text=bool(streaming_args.all_text), pos_mode=streaming_args.pos_mode,
-                       last_cache_position=streaming_args.last_cache_position, force_tokens=force_tokens)
+                       last_cache_position=streaming_args.last_cache_position, force_tokens=force_tokens, top_k=top_k, top_p=top_p)
     streaming_args.last_cache_position = eng.last_position          # qwen2/model_forward.py:117
     # the reference pads streaming_args.input_ids by one per forward (qwen2/language_forward.py:323-325)
     if streaming_args.input_ids is not None:
@@ -102,6 +102,19 @@ def convert_qwen2_to_streaming(model, ops=None, **engine_kw):
     sd = {k: v for k, v in model.state_dict().items()}
     if cfg.text.tie_word_embeddings:
         sd.pop("lm_head.weight", None)
-    model._svlm_engine = SvlmEngine(cfg, sd, device, ops=ops, **engine_kw)
+    eng = model._svlm_engine = SvlmEngine(cfg, sd, device, ops=ops, **engine_kw)
+    # HF's generate() merges the checkpoint's generation_config into every call: its top_k / top_p become logits warpers under
+    # do_sample=True (stock Qwen2-VL checkpoints ship top_k = 1, i.e. effectively greedy) and its eos_token_id ends a turn
+    gc = getattr(model, "generation_config", None)
+    if gc is not None:
+        if getattr(gc, "top_k", None) is not None:
+            eng.default_top_k = int(gc.top_k)
+        if getattr(gc, "top_p", None) is not None:
+            eng.default_top_p = float(gc.top_p)
+        eos = getattr(gc, "eos_token_id", None)
+        if eos is not None:
+            eos = tuple(int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos]))
+            cfg.eos_token_ids = eos
+            eng.eos_dev = torch.tensor(list(eos), dtype=torch.int32, device=eng.device)
     model.generate = MethodType(streaming_generate, model)
     return model

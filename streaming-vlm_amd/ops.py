@@ -394,6 +394,22 @@ class HipOps:
         check(self.lib.svlm_penalty_argmax(_ptr(logits), logits.numel(), _ptr(seen), float(penalty), _ptr(suppress), n_sup,
                                            _ptr(tok_buf), _ptr(state), int(advance_kv), _ptr(ws), _stream()), "svlm_penalty_argmax")
 
+    def penalty_sample(self, logits, seen, penalty, suppress, temperature, top_k, top_p, rng, tok_buf, state, advance_kv, ws):
+        """One draw from the processed distribution (repetition penalty -> temperature -> top-k -> top-p -> multinomial) + token
+        feedback; rng: uint32[2] seed in device memory."""
+        _req(logits, torch.float32, "sample.logits", 1); _req(tok_buf, torch.int32, "sample.tok_buf", 1)
+        _req(state, torch.int32, "sample.state", 1); _req(rng, torch.int32, "sample.rng", 1); _req(ws, torch.float32, "sample.ws", 1)
+        if seen is not None:
+            _req(seen, torch.uint8, "sample.seen", 1); assert seen.numel() == logits.numel()
+        n_sup = 0
+        if suppress is not None:
+            _req(suppress, torch.int32, "sample.suppress", 1)
+            n_sup = suppress.numel()
+        assert state.numel() >= 2 and rng.numel() >= 2 and ws.numel() * 4 >= self.lib.svlm_argmax_ws_bytes()
+        check(self.lib.svlm_penalty_sample(_ptr(logits), logits.numel(), _ptr(seen), float(penalty), _ptr(suppress), n_sup, float(temperature),
+                                           int(top_k), float(top_p), _ptr(rng), _ptr(tok_buf), _ptr(state), int(advance_kv), _ptr(ws),
+                                           _stream()), "svlm_penalty_sample")
+
     # ------------------------------------------------------------------ fused decode step
     def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
         _req(x, BF16, "dec_qkv.x", 1); _req(ln_w, BF16, "dec_qkv.ln_w", 1); _req(W, BF16, "dec_qkv.W", 2)
@@ -413,7 +429,8 @@ class HipOps:
         assert N % 2 == 0 and h.numel() == N // 2 and x.numel() == K == ln_w.numel()
         check(self.lib.svlm_dec_gate_up(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(h), N // 2, K, _stream()), "svlm_dec_gate_up")
 
-    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws):
+    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws, temperature=None, rng=None, state=None):
+        """`temperature` + `rng` (uint32[2] seed on the device) + `state`: Gumbel-max temperature sampling in the candidates."""
         _req(x, BF16, "dec_lm_head.x", 1); _req(ln_w, BF16, "dec_lm_head.ln_w", 1); _req(W, BF16, "dec_lm_head.W", 2)
         _req(logits, torch.float32, "dec_lm_head.logits", 1); _req(ws, torch.float32, "dec_lm_head.ws", 1)
         V, K = W.shape
@@ -425,6 +442,12 @@ class HipOps:
         if suppress is not None:
             _req(suppress, torch.int32, "dec_lm_head.suppress", 1)
             n_sup = suppress.numel()
+        if rng is not None:
+            _req(rng, torch.int32, "dec_lm_head.rng", 1); _req(state, torch.int32, "dec_lm_head.state", 1)
+            check(self.lib.svlm_dec_lm_head_sample(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(logits), _ptr(seen), float(penalty),
+                                                   _ptr(suppress), n_sup, _ptr(ws), V, K, float(temperature), _ptr(rng), _ptr(state), _stream()),
+                  "svlm_dec_lm_head_sample")
+            return
         check(self.lib.svlm_dec_lm_head(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(logits), _ptr(seen), float(penalty),
                                         _ptr(suppress), n_sup, _ptr(ws), V, K, _stream()), "svlm_dec_lm_head")
 

@@ -212,13 +212,33 @@ class RefOps:
         I = W.shape[0] // 2
         h.copy_((F.silu(y[:, :I]) * y[:, I:])[0])
 
-    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws):
+    def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws, temperature=None, rng=None, state=None):
         logits.copy_(F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W)[0].float())
-        self._pending = (logits, seen, penalty, suppress)
+        self._pending = (logits, seen, penalty, suppress, temperature, rng)
 
     def argmax_finish(self, ws, V, seen, tok_buf, state, advance_kv):
-        logits, seen_, penalty, suppress = self._pending
+        logits, seen_, penalty, suppress, temperature, rng = self._pending
+        if rng is not None:
+            return self.penalty_sample(logits, seen_, penalty, suppress, temperature, 0, 1.0, rng, tok_buf, state, advance_kv, ws)
         self.penalty_argmax(logits, seen_, penalty, suppress, tok_buf, state, advance_kv, ws)
+
+    def penalty_sample(self, logits, seen, penalty, suppress, temperature, top_k, top_p, rng, tok_buf, state, advance_kv, ws=None):
+        """CPU stand-in of svlm_penalty_sample: the oracle's processors + a multinomial draw seeded by (rng, token index)."""
+        from oracle.generate import warp_scores
+        sc = logits.clone()
+        if seen is not None:
+            m = seen.bool()
+            sc[m] = torch.where(sc[m] < 0, sc[m] * penalty, sc[m] / penalty)
+        if suppress is not None:
+            sc[suppress.long()] = float("-inf")
+        cur = int(state[1]) + 1
+        g = torch.Generator().manual_seed((int(rng[0]) & 0xFFFFFFFF) * 1000003 + (int(rng[1]) & 0xFFFFFFFF) * 7919 + cur)
+        tok = int(torch.multinomial(torch.softmax(warp_scores(sc, temperature, top_k, top_p), dim=-1), 1, generator=g))
+        tok_buf[cur] = tok
+        state[1] = cur
+        state[0] += advance_kv
+        if seen is not None:
+            seen[tok] = 1
 
     def penalty_argmax(self, logits, seen, penalty, suppress, tok_buf, state, advance_kv, ws=None):
         sc = logits.clone()

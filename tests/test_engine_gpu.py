@@ -351,6 +351,15 @@ def test_sampling_recompute_and_teacher_forcing_run_on_the_device(tmp_path):
         S.streaming_inference(model=model, do_sample=True, temperature=0.9, generator=g, ids_log=log, **kw)
         outs.append([e["new"] for e in log])
     assert outs[0] == outs[1]
+    # the captured decode graph draws fresh noise at every step and every call: no token pattern repeats across the chunks
+    assert len({tuple(t) for t in outs[0]}) == len(outs[0])
+    # top_k = 1 (what stock Qwen2-VL checkpoints ship in their generation_config) is the greedy stream, token for token
+    cfg, sd, model = _tiny_model()
+    ga, gb = [], []
+    S.streaming_inference(model=model, do_sample=True, temperature=0.9, top_k=1, suppress_eos=True, ids_log=ga, **kw)
+    cfg, sd, model = _tiny_model()
+    S.streaming_inference(model=model, do_sample=False, suppress_eos=True, ids_log=gb, **kw)
+    assert [e["new"] for e in ga] == [e["new"] for e in gb]
     cfg, sd, model = _tiny_model()
     a, b = [], []
     S.streaming_inference(model=model, do_sample=False, suppress_eos=True, recompute=True, ids_log=a, **kw)

@@ -342,3 +342,25 @@ def test_efficiency_harness_emits_the_reference_document(tiny, tmp_path):
         assert os.path.basename(path).startswith(em.MODE_NAMES[mode] + "__Qwen2__random:tiny__") and json.load(open(path))["meta"] == p["meta"]
         if mode == "b":          # the KV cache stops growing once the 6-chunk window is full
             assert p["svlm"]["kv_len_last"] < 16 * 40
+
+
+def test_sampling_with_top_k_1_is_greedy_in_oracle_and_engine(tiny):
+    """HF merges the checkpoint's generation_config into generate(): stock Qwen2-VL checkpoints carry top_k = 1, which turns the
+    reference's do_sample=True call into the greedy stream.  Oracle warpers and the engine's sampling path both must say so."""
+    from oracle import generate as og
+    cfg, sd = tiny
+    sc = torch.randn(1000, generator=torch.Generator().manual_seed(0))
+    w = og.warp_scores(sc, 0.9, 1, 0.001)
+    assert int(torch.isfinite(w).sum()) == 1 and int(torch.argmax(w)) == int(torch.argmax(sc))
+    w = og.warp_scores(sc, 1.0, 5, 1.0)
+    assert int(torch.isfinite(w).sum()) == 5
+    p = torch.softmax(og.warp_scores(sc, 1.0, 0, 0.5), -1)
+    kept = torch.sort(p[p > 0], descending=True).values
+    full = torch.sort(torch.softmax(sc, -1), descending=True).values
+    assert abs(float(full[:kept.numel()].sum()) - 0.5) < float(full[kept.numel() - 1]) + 1e-6          # smallest prefix reaching 0.5
+    kw = dict(processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps", model_base="Qwen2", duration=3, quiet=True,
+              max_new_tokens=6, suppress_eos=True)
+    a, b = [], []
+    S.streaming_inference(model=_model(cfg, sd), do_sample=True, temperature=0.9, top_k=1, ids_log=a, **kw)
+    S.streaming_inference(model=_model(cfg, sd), do_sample=False, ids_log=b, **kw)
+    assert [e["new"] for e in a] == [e["new"] for e in b]

@@ -512,3 +512,102 @@ def test_resize_bicubic_aa_u8_bit_exact(ops, T, H, W, h, w):
     assert torch.equal(again, got)
     with pytest.raises(Exception):
         ops.resize_u8(x.cuda().float(), h, w)
+
+
+# ----------------------------------------------------------------------------- device-side sampling
+def _chi2_p(counts, probs, n):
+    """p-value of the observed token counts against `probs`; cells pooled until each expects >= 25 draws."""
+    from scipy import stats
+    order = np.argsort(-probs)
+    obs, exp, o_acc, e_acc = [], [], 0.0, 0.0
+    for i in order:
+        o_acc += counts[i]; e_acc += probs[i] * n
+        if e_acc >= 25:
+            obs.append(o_acc); exp.append(e_acc); o_acc = e_acc = 0.0
+    if e_acc > 0 and obs:
+        obs[-1] += o_acc; exp[-1] += e_acc
+    exp = np.array(exp) * (np.sum(obs) / np.sum(exp))
+    return float(stats.chisquare(obs, exp).pvalue), len(obs)
+
+
+@pytest.mark.parametrize("V,temperature,top_k,top_p,penalty", [
+    (5000, 0.9, 0, 1.0, 1.05),       # the reference's call: T = 0.9, repetition penalty 1.05 -- Gumbel-max in the argmax kernels
+    (5000, 0.7, 40, 1.0, 1.0),       # top-k
+    (5000, 1.0, 0, 0.8, 1.0),        # nucleus only (survivors beyond 2048 are cut: the nucleus here is far smaller)
+    (5000, 0.9, 50, 0.9, 1.05),      # HF defaults-style mix
+    (151936, 0.9, 0, 1.0, 1.05),     # full vocabulary
+    (151936, 0.9, 0, 0.95, 1.05),    # full vocabulary, nucleus weighed against all of it
+])
+def test_penalty_sample_distribution(ops, V, temperature, top_k, top_p, penalty):
+    """svlm_penalty_sample against the oracle's restatement of HF's processors (oracle/generate.py:warp_scores + softmax):
+    1e5 draws from fixed logits, chi-square over pooled cells (p > 1e-4); every draw must fall inside the survivor set."""
+    from oracle import generate as og
+    N = 100_000
+    g = torch.Generator().manual_seed(V + top_k)
+    logits = (torch.randn(V, generator=g) * 2.0)
+    seen_ids = torch.randint(0, V, (64,), generator=g)
+    sup = torch.tensor([7, 11], dtype=torch.int32)
+    sc = og.repetition_penalty(logits.clone(), seen_ids.tolist(), penalty)
+    sc[sup.long()] = float("-inf")
+    probs = torch.softmax(og.warp_scores(sc, temperature, top_k, top_p), dim=-1).double().numpy()
+    seen = torch.zeros(V, dtype=torch.uint8)
+    seen[seen_ids] = 1
+    d_logits, d_seen, d_sup = logits.cuda(), seen.cuda(), sup.cuda()
+    tok_buf = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+    state = torch.tensor([0, -1], dtype=torch.int32, device="cuda")
+    rng = torch.tensor([12345, 678], dtype=torch.int32, device="cuda")
+    ws = ops.sampling_ws(V, "cuda")
+    seen_arg = d_seen if penalty != 1.0 else None
+    seen0 = seen.cuda()
+    for _ in range(N):
+        ops.penalty_sample(d_logits, seen_arg, penalty, d_sup, temperature, top_k, top_p, rng, tok_buf, state, 0, ws)
+        if seen_arg is not None:
+            d_seen.copy_(seen0)          # the kernel marks the token it drew: every draw must see the same `seen` set
+    torch.cuda.synchronize()
+    toks = tok_buf[:N].cpu().numpy()
+    assert int(state[1]) == N - 1
+    counts = np.bincount(toks, minlength=V).astype(np.float64)
+    assert counts[probs == 0].sum() == 0, "a draw fell outside the survivor set"
+    p, cells = _chi2_p(counts, probs, N)
+    print(f"[sample V={V} T={temperature} k={top_k} p={top_p}] {cells} cells, chi-square p = {p:.3g}, support {int((probs > 0).sum())}")
+    assert p > 1e-4, p
+
+
+def test_sampling_degenerate_cases_are_the_argmax(ops):
+    """top_k = 1 and T -> 0 must reproduce the greedy token every time (streaming_generate_qwen.py:99)."""
+    V = 3000
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(V, generator=g) * 3.0
+    want = int(torch.argmax(logits))
+    d_logits = logits.cuda()
+    tok_buf = torch.zeros(257, dtype=torch.int32, device="cuda")
+    rng = torch.tensor([1, 2], dtype=torch.int32, device="cuda")
+    ws = ops.sampling_ws(V, "cuda")
+    for temperature, top_k, top_p in ((0.9, 1, 1.0), (1e-3, 0, 1.0), (1e-3, 20, 0.9), (1.0, 0, 1e-6)):
+        state = torch.tensor([0, -1], dtype=torch.int32, device="cuda")
+        for _ in range(256):
+            ops.penalty_sample(d_logits, None, 1.0, None, temperature, top_k, top_p, rng, tok_buf, state, 0, ws)
+        assert (tok_buf[:256].cpu() == want).all(), (temperature, top_k, top_p)
+
+
+def test_dec_lm_head_sample_distribution(ops, ref):
+    """The fused decode-step form: final norm -> lm_head -> Gumbel-max candidates -> svlm_argmax_finish, 3e4 draws against
+    softmax(penalised logits / T) of the kernel's own logits row."""
+    from oracle import generate as og
+    H, V, N, T = 256, 4096, 30_000, 0.9
+    x, lnw, W = rnd((H,), 1, 1.0), rnd((H,), 2, 0.1) + 1.0, rnd((V, H), 3, 0.08)
+    dx, dl, dW = x.cuda(), lnw.to(BF16).cuda(), W.cuda()
+    logits = torch.zeros(V, dtype=torch.float32, device="cuda")
+    ws = ops.sampling_ws(V, "cuda")
+    tok_buf = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+    state = torch.tensor([0, -1], dtype=torch.int32, device="cuda")
+    rng = torch.tensor([99, 7], dtype=torch.int32, device="cuda")
+    for _ in range(N):
+        ops.dec_lm_head(dx, dl, 1e-6, dW, logits, None, 1.0, None, ws, temperature=T, rng=rng, state=state)
+        ops.argmax_finish(ws, V, None, tok_buf, state, 0)
+    torch.cuda.synchronize()
+    probs = torch.softmax(logits.cpu() / T, dim=-1).double().numpy()
+    counts = np.bincount(tok_buf[:N].cpu().numpy(), minlength=V).astype(np.float64)
+    p, cells = _chi2_p(counts, probs, N)
+    print(f"[dec_lm_head_sample] {cells} cells, chi-square p = {p:.3g}")
+    assert p > 1e-4, p
