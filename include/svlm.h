@@ -102,6 +102,19 @@ int svlm_resize_bicubic_aa_u8(const void* src, void* dst, int planes, int H, int
                               const float* wt_x, int Kx, const int* ymin, const int* ysize, const float* wt_y, int Ky, void* ws,
                               long long ws_bytes, void* stream);
 
+/* ---- FP8 (OCP e4m3) ViT GEMMs of BASELINE configs[4] ("fp8 MFMA ViT path").  The reference has no fp8 path; the recipe is the
+ * build's: activations get one dynamic fp32 scale per ROW (max|row| / 448), weights one static scale per OUTPUT CHANNEL, both
+ * sides round-to-nearest-even to e4m3, the products accumulate in fp32 on v_mfma_f32_16x16x32_fp8_fp8 and the scales are applied
+ * before the bf16 epilogue.  oracle/model.py:linear_fp8 restates it; parity is HIP vs that oracle leg.
+ * svlm_quant_rows_fp8: x bf16 (rows, ldx) -> q fp8 (rows, ldq) + scale fp32 (rows).
+ * svlm_gemm_fp8: C = epi((A8 . W8^T) * a_scale[m] * w_scale[n]) with the epilogue (bias, act, residual) and the optional fused
+ * norm (norm_w / norm_b / XN as svlm_gemm_bf16_norm) of the bf16 GEMM; K % 128 == 0; ws = fp32 split-K scratch.
+ * replaces: the ViT Linear calls at qwen2/vision_forward.py:14,33,43-49 and the merger MLP (:80) in the fp8 configuration. */
+int svlm_quant_rows_fp8(const void* x, int ldx, void* q, int ldq, float* scale, int rows, int cols, void* stream);
+int svlm_gemm_fp8(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
+                  const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
+                  const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream);
+
 /* In-place 2-D rope on the q and k parts of the fused ViT qkv buffer (N,3,H,d); cosT/sinT fp32 (N,d/2).
  * replaces: apply_rotary_pos_emb_vision (qwen2/vision_forward.py:27). */
 int svlm_vit_rope(void* qkv, const float* cosT, const float* sinT, int N, int H, int d, void* stream);

@@ -543,6 +543,8 @@ extern "C" int svlm_layernorm(const void* x, const void* w, const void* b, void*
 static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                      void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream,
                      const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn);
+int svlm_gemm_reduce_launch(const float* partial, int splits, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
+                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream);
 
 extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                               void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream) {
@@ -713,6 +715,14 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   }
   int rc = svlm_check_launch("svlm_gemm_bf16");
   if (rc) return rc;
+  return svlm_gemm_reduce_launch(partial, splits, bias, residual, ldr, C, ldc, M, N, act, norm_w, norm_b, eps, XN, ldxn, stream);
+}
+
+// Tail shared by the bf16 and fp8 GEMMs: split-K reduce (+ epilogue), with the norm of the output row folded in when there is one.
+int svlm_gemm_reduce_launch(const float* partial, int splits, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
+                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
   if (splits > 1 && norm_w != nullptr && N <= 2048 * RN_IT) {      // reduce + RMSNorm of the reduced row in one launch
     gemm_splitk_reduce_norm_kernel<<<M, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C,
                                                                 ldc, M, N, act, (const bf16_t*)norm_w, (const bf16_t*)norm_b, eps, (bf16_t*)XN, ldxn);

@@ -117,6 +117,42 @@ class _VitRun:
             self.g = torch.empty((N, vc.mlp_padded), dtype=BF16, device=eng.device)
         else:
             self.f = torch.empty((N, vc.mlp_hidden), dtype=BF16, device=eng.device)
+        self.fp8 = eng.vit_fp8
+        if self.fp8:            # fp8 operand images + one fp32 scale per row of every GEMM input
+            f8 = torch.float8_e4m3fn
+            self.q_e = torch.empty((N, E), dtype=f8, device=eng.device)
+            self.q_f = torch.empty((N, vc.mlp_hidden), dtype=f8, device=eng.device)
+            self.s_row = torch.empty((N,), dtype=torch.float32, device=eng.device)
+
+    def _blocks_fp8(self, lo: int, hi: int):
+        """The Qwen2 tower with its four Linears per block on the fp8 MFMA path (BASELINE configs[4]): every GEMM input is
+        quantised per row right before its GEMM (svlm_quant_rows_fp8), weights were quantised per output channel at load."""
+        o, vc = self.eng.ops, self.eng.cfg.vision
+        Hh, d = vc.num_heads, vc.head_dim
+        scale = 1.0 / math.sqrt(d)
+        x, h, qkv, a, f = self.x, self.h, self.qkv, self.a, self.f
+        blocks = self.eng.w.vit
+        w8 = self.eng.vit_w8
+        if lo < hi and not self._h_is_norm1:
+            o.layernorm(x, blocks[lo]["n1w"], blocks[lo]["n1b"], 1e-6, out=h)
+        for bi in range(lo, hi):
+            bw, b8 = blocks[bi], w8[bi]
+            o.quant_rows_fp8(h, self.q_e, self.s_row)
+            o.gemm_fp8(self.q_e, self.s_row, *b8["qkv"], bias=bw["qkv_b"], out=qkv)
+            o.vit_rope(qkv, self.cosT, self.sinT, Hh, d)
+            o.vit_attn(qkv, self.n_seq, self.seq_len, Hh, d, scale, out=a)
+            o.quant_rows_fp8(a, self.q_e, self.s_row)
+            o.gemm_fp8(self.q_e, self.s_row, *b8["proj"], bias=bw["proj_b"], residual=x, out=x, norm_w=bw["n2w"], norm_b=bw["n2b"], out_norm=h)
+            o.quant_rows_fp8(h, self.q_e, self.s_row)
+            o.gemm_fp8(self.q_e, self.s_row, *b8["fc1"], bias=bw["fc1_b"], out=f, act=ACT_QUICK_GELU)
+            o.quant_rows_fp8(f, self.q_f, self.s_row)
+            if bi + 1 < len(blocks):
+                nb = blocks[bi + 1]
+                o.gemm_fp8(self.q_f, self.s_row, *b8["fc2"], bias=bw["fc2_b"], residual=x, out=x, norm_w=nb["n1w"], norm_b=nb["n1b"], out_norm=h)
+            else:
+                o.gemm_fp8(self.q_f, self.s_row, *b8["fc2"], bias=bw["fc2_b"], residual=x, out=x)
+        if lo < hi:
+            self._h_is_norm1 = hi < len(blocks)
 
     def _blocks_2_5(self, lo: int, hi: int):
         """Qwen2_5_VLVisionBlock x (hi - lo): RMSNorm -> qkv -> 2-D rope -> window / full attention -> proj + residual ->
@@ -151,6 +187,8 @@ class _VitRun:
     def blocks(self, lo: int, hi: int):
         if self.q25:
             return self._blocks_2_5(lo, hi)
+        if self.fp8:
+            return self._blocks_fp8(lo, hi)
         o, vc = self.eng.ops, self.eng.cfg.vision
         Hh, d = vc.num_heads, vc.head_dim
         scale = 1.0 / math.sqrt(d)
@@ -182,6 +220,11 @@ class _VitRun:
             o.layernorm(self.x, mg["ln_w"], mg["ln_b"], 1e-6, out=self.h)
         m2 = vc.spatial_merge_size ** 2
         hm = self.h.view(self.N // m2, vc.embed_dim * m2)
+        if self.fp8:
+            m8 = self.eng.vit_w8[-1]
+            g1 = o.gemm_fp8(*o.quant_rows_fp8(hm), *m8["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
+            out = o.gemm_fp8(*o.quant_rows_fp8(g1), *m8["w2"], bias=mg["b2"])
+            return out
         g1 = o.gemm(hm, mg["w0"], bias=mg["b0"], act=ACT_GELU_ERF)
         out = o.gemm(g1, mg["w2"], bias=mg["b2"])
         if self.q25:           # back from window order to token order (qwen2_5/vision_forward.py:96-97)
@@ -191,7 +234,8 @@ class _VitRun:
 
 class SvlmEngine:
     def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, max_len: int = 4096, max_new_tokens: int = 32,
-                 decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None, kv_slack: float = 1.0, kv_page_tokens: int = 16):
+                 decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None, kv_slack: float = 1.0, kv_page_tokens: int = 16,
+                 vit_fp8: bool = False):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()                      # raises when the HIP extension / GPU is missing
@@ -202,6 +246,19 @@ class SvlmEngine:
         tc, vc = cfg.text, cfg.vision
         if tc.head_dim != 128 or sum(tc.mrope_section) * 2 != tc.head_dim:
             raise ValueError("LLM head_dim must be 128 with mrope sections summing to 64")
+        # BASELINE configs[4]: the vision tower's Linears on the fp8 MFMA path (svlm_gemm_fp8), weights quantised once here
+        self.vit_fp8 = bool(vit_fp8)
+        if self.vit_fp8:
+            if vc.arch != "qwen2" or vc.embed_dim % 128 or vc.mlp_hidden % 128:
+                raise ValueError("vit_fp8 needs the Qwen2-VL tower with widths that are multiples of 128 (LiveCC-7B / Qwen2-VL)")
+
+            def q8(wt):          # per output channel: s = max|row| / 448, q = rne_e4m3(w / s)   (oracle/model.py:quant_rows_fp8)
+                wf = wt.float()
+                amax = wf.abs().amax(dim=1, keepdim=True)
+                s8 = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+                return (wf / s8).to(torch.float8_e4m3fn).contiguous(), s8.reshape(-1).contiguous()
+            self.vit_w8 = [dict(qkv=q8(b["qkv_w"]), proj=q8(b["proj_w"]), fc1=q8(b["fc1_w"]), fc2=q8(b["fc2_w"])) for b in self.w.vit]
+            self.vit_w8.append(dict(w0=q8(self.w.merger["w0"]), w2=q8(self.w.merger["w2"])))
         self.max_len = int(max_len)
         self.max_new = int(max_new_tokens)
         self.kv_slack, self.kv_page_tokens = float(kv_slack), int(kv_page_tokens)      # KV pool head-room over max_len, page size
@@ -347,7 +404,7 @@ class SvlmEngine:
         run, pend[4] = pend[4], None
         main = torch.cuda.current_stream()
         main.wait_event(pend[2])                       # the side stream's blocks: long finished by now
-        for t in (run.x, run.h, run.qkv, run.a, run.f) + ((run.g,) if run.q25 else ()):
+        for t in (run.x, run.h, run.qkv, run.a, run.f) + ((run.g,) if run.q25 else ()) + ((run.q_e, run.q_f, run.s_row) if run.fp8 else ()):
             t.record_stream(main)                      # allocated on the side stream, used here
         depth = self.cfg.vision.depth
         run.blocks(depth - min(self.vit_tail, depth), depth)

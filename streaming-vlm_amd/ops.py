@@ -127,6 +127,52 @@ class HipOps:
                                            _ptr(out_norm), out_norm.stride(0), _stream()), "svlm_gemm_bf16_norm")
         return out, out_norm
 
+    # ------------------------------------------------------------------ fp8 (BASELINE configs[4]: ViT GEMMs on the fp8 MFMA path)
+    FP8 = torch.float8_e4m3fn
+
+    def quant_rows_fp8(self, x, q=None, scale=None):
+        """bf16 (rows, cols) -> (fp8 e4m3 (rows, cols), fp32 scale per row): scale = max|row| / 448, q = rne(x / scale)."""
+        _req(x, BF16, "quant_fp8.x", 2)
+        rows, cols = x.shape
+        if q is None:
+            q = torch.empty((rows, cols), dtype=self.FP8, device=x.device)
+        if scale is None:
+            scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        _req(q, self.FP8, "quant_fp8.q", 2); _req(scale, torch.float32, "quant_fp8.scale", 1)
+        assert tuple(q.shape) == (rows, cols) and scale.numel() == rows
+        check(self.lib.svlm_quant_rows_fp8(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(scale), rows, cols, _stream()), "svlm_quant_rows_fp8")
+        return q, scale
+
+    def gemm_fp8(self, A8, a_scale, W8, w_scale, bias=None, residual=None, out=None, act=ACT_NONE, norm_w=None, norm_b=None, eps=1e-6,
+                 out_norm=None):
+        """out = epi((A8 @ W8^T) * a_scale[:, None] * w_scale[None, :]); with norm_w: out_norm = norm(out) as `gemm_norm`."""
+        _req(A8, self.FP8, "gemm_fp8.A", 2); _req(W8, self.FP8, "gemm_fp8.W", 2)
+        _req(a_scale, torch.float32, "gemm_fp8.a_scale", 1); _req(w_scale, torch.float32, "gemm_fp8.w_scale", 1)
+        M, K = A8.shape
+        N, K2 = W8.shape
+        if K != K2 or a_scale.numel() != M or w_scale.numel() != N:
+            raise _lib.SvlmError(f"gemm_fp8: A {tuple(A8.shape)} W {tuple(W8.shape)} scales {a_scale.numel()}/{w_scale.numel()}")
+        if out is None:
+            out = torch.empty((M, N), dtype=BF16, device=A8.device)
+        _req(out, BF16, "gemm_fp8.out", 2)
+        assert tuple(out.shape) == (M, N)
+        ldr = 0
+        if residual is not None:
+            _req(residual, BF16, "gemm_fp8.residual", 2); assert tuple(residual.shape) == (M, N)
+            ldr = residual.stride(0)
+        if bias is not None:
+            _req(bias, BF16, "gemm_fp8.bias", 1); assert bias.numel() == N
+        ldxn = 0
+        if norm_w is not None:
+            _req(norm_w, BF16, "gemm_fp8.norm_w", 1); _req(out_norm, BF16, "gemm_fp8.out_norm", 2)
+            assert norm_w.numel() == N and tuple(out_norm.shape) == (M, N)
+            ldxn = out_norm.stride(0)
+        ws = self._ws(A8.device)
+        check(self.lib.svlm_gemm_fp8(_ptr(A8), A8.stride(0), _ptr(a_scale), _ptr(W8), W8.stride(0), _ptr(w_scale), _ptr(bias), _ptr(residual), ldr,
+                                     _ptr(out), out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _ptr(norm_w), _ptr(norm_b), float(eps),
+                                     _ptr(out_norm), ldxn, _stream()), "svlm_gemm_fp8")
+        return out
+
     def gemv(self, x, W, bias=None, residual=None, out=None, out_f32=None, act=ACT_NONE):
         _req(x, BF16, "gemv.x"); _req(W, BF16, "gemv.W", 2)
         N, K = W.shape

@@ -196,6 +196,31 @@ class RefOps:
         out[:T] = o.transpose(0, 1).reshape(T, Hq * D)
         return out
 
+    def quant_rows_fp8(self, x, q=None, scale=None):
+        qv, s = om.quant_rows_fp8(x)
+        qv, s = qv.to(torch.float8_e4m3fn), s.reshape(-1)
+        if q is not None:
+            q.copy_(qv); scale.copy_(s)
+            return q, scale
+        return qv, s
+
+    def gemm_fp8(self, A8, a_scale, W8, w_scale, bias=None, residual=None, out=None, act=0, norm_w=None, norm_b=None, eps=1e-6, out_norm=None):
+        y = (A8.float() @ W8.float().t()) * (a_scale.reshape(-1, 1) * w_scale.reshape(1, -1))
+        if bias is not None:
+            y = y + bias.float()
+        y = _act(y.to(torch.bfloat16), act)
+        if residual is not None:
+            y = y + residual
+        if out is None:
+            out = torch.empty_like(y)
+        out.copy_(y)
+        if norm_w is not None:
+            if norm_b is not None:
+                out_norm.copy_(F.layer_norm(out, (out.shape[-1],), norm_w, norm_b, eps))
+            else:
+                out_norm.copy_(om.rms_norm(out, norm_w, eps))
+        return out
+
     def mark_seen(self, ids, n, seen):
         seen[ids[:n].long()] = 1
 
