@@ -54,6 +54,12 @@ def main():
     ap.add_argument("--sampling", default="greedy", choices=["greedy", "temperature", "hf-default"],
                     help="token choice: greedy (the contract's line, BASELINE configs); temperature = the reference's call (do_sample, T 0.9, "
                          "Gumbel-max in the captured graph); hf-default = the same with HF's default top_k 50 (the filter kernel)")
+    ap.add_argument("--scenario", default="stream", choices=["stream", "dense_prefill"],
+                    help="stream: the contract's line (BASELINE configs[1]/[2]); dense_prefill: configs[4] -- `--prefill-chunks` chunks of frames "
+                         "go through ONE forward (ViT in 8-frame-grid passes, LLM prefill in 4096-row passes), then the KV cache is compacted "
+                         "to sink+window and the stream continues live; reports prefill frames/s beside the steady rate")
+    ap.add_argument("--prefill-chunks", type=int, default=300, help="dense_prefill: chunks piled into the opening forward (300 = 5 min)")
+    ap.add_argument("--vit-fp8", action="store_true", help="vision tower Linears on the fp8 MFMA path (svlm_gemm_fp8; configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -84,11 +90,17 @@ def main():
     # more untimed chunk, so that each timed chunk carries exactly one look-ahead ViT pass (the first timed chunk's frames were
     # encoded under the last warmup chunk; the last timed chunk encodes the trailing chunk's).
     fill = max(0, -(-(args.sink + args.window) // (tok_per_frame + 19 + args.new_tokens)) + 1 - args.warmup)
+    dense = args.prefill_chunks if args.scenario == "dense_prefill" else 0
+    if dense:          # the opening forward holds every piled chunk; the window is full (and over-full) right behind it
+        fill = dense
+        max_len = max(max_len, 64 + dense * (tok_per_frame + 24) + 2 * chunk_tokens)
     first_timed = fill + args.warmup
     n_chunks = first_timed + args.steps + 1
     log(f"rank {rank}/{world}: building {cfg.name} random weights on {dev}")
     sd = random_state_dict(cfg, 0, dev)
-    model = S.StreamingQwen2VL(cfg, sd, dev, max_len=max_len, max_new_tokens=args.new_tokens)
+    model = S.StreamingQwen2VL(cfg, sd, dev, max_len=max_len, max_new_tokens=args.new_tokens, vit_fp8=args.vit_fp8)
+    if dense:
+        model._svlm_engine.section_events = []
     log("engine ready; staging the synthetic stream in HBM")
     # inputs resident in HBM before timing; long runs cycle through 128 distinct chunks
     period = 128 if n_chunks > 256 else 0
@@ -114,6 +126,17 @@ def main():
         stamps.append(time.perf_counter())
         if i == 0:
             log(f"stream started ({fill} chunks to fill the KV window + {args.warmup} warmup chunks)")
+            if dense:
+                fence()
+                t["dense0"] = time.perf_counter()
+        if dense and i == dense:
+            fence()
+            t["dense1"] = time.perf_counter()
+            t["dense_kv"] = kvlog[-1]["kv_len"]
+            log(f"dense prefill of {dense} chunks done in {t['dense1'] - t['dense0']:.2f} s (KV {t['dense_kv']} rows)")
+        if dense and i == dense + 1:
+            fence()
+            t["compact1"] = time.perf_counter()
         if i == first_timed:
             fence()
             kv_now = kvlog[-1]["kv_len"] if kvlog else 0
@@ -131,7 +154,7 @@ def main():
                           kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=args.sampling != "greedy",
                           temperature=0.9, top_k={"greedy": None, "temperature": 0, "hf-default": 50}[args.sampling], top_p=1.0,
                           max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk,
-                          ids_log=kvlog)
+                          ids_log=kvlog, dense_prefill_chunks=dense)
     fence()
     kv_steady[0] = kvlog[-1]["kv_len"]
     kv_max = max(e["kv_len"] for e in kvlog)
@@ -140,6 +163,8 @@ def main():
     elapsed = t["t1"] - t["t0"]
     log(f"timed region done: {elapsed:.3f} s for {args.steps} chunks")
     frames = args.steps * frames_per_chunk
+    if dense:          # piled chunks produce no ids_log / token_counts entries: the first answered chunk is the last piled one
+        counts = [0] * (dense - 1) + counts
     tokens = sum(counts[first_timed:first_timed + args.steps])
     agg = MS.aggregate(frames, tokens, elapsed, dist, dev if backend == "nccl" else "cpu")
     t_max, fps_total, tps_total, per_gpu_fps = agg["t_max"], agg["frames_per_sec"], agg["tokens_per_sec"], agg["per_rank_frames_per_sec"]
@@ -158,6 +183,21 @@ def main():
         "chunk_ms_per_token": round(1e3 * t_max / max(1, tokens), 4),
         "kv_pool": {k: int(v) for k, v in cache_stats.items()},
     }
+    if dense:
+        ev = {}
+        for name, a, b in model._svlm_engine.section_events[:2]:          # the opening forward's ViT and LLM-prefill phases
+            ev[name] = a.elapsed_time(b) / 1e3
+        fr = dense * frames_per_chunk
+        out["scenario"] = "dense_prefill"
+        out["config"]["workload"] += f"; opened by a dense prefill of {fr} frames ({dense} chunks in one forward)" + (", fp8 ViT" if args.vit_fp8 else "")
+        out["dense_prefill"] = {"frames": fr, "chunks": dense, "seconds": round(t["dense1"] - t["dense0"], 3),
+                                "frames_per_sec": round(fr / (t["dense1"] - t["dense0"]), 2), "vit_seconds": round(ev.get("vit", 0.0), 3),
+                                "vit_frames_per_sec": round(fr / ev["vit"], 1) if ev.get("vit") else None,
+                                "llm_prefill_seconds": round(ev.get("prefill", 0.0), 3), "prompt_rows": t["dense_kv"] - args.new_tokens + 1,
+                                "kv_rows_after": t["dense_kv"],
+                                # first live chunk: sink/window eviction compacts the cache (slot-table edit + page recycling), then a normal chunk
+                                "first_live_chunk_ms": round(1e3 * (t["compact1"] - t["dense1"]), 2), "kv_rows_live": kv_steady[0],
+                                "vit_fp8": bool(args.vit_fp8)}
     if args.steps >= 400:      # drift over a long stream: mean chunk time of the first / last 100 timed chunks
         d = [1e3 * (b - a) for a, b in zip(stamps[first_timed:first_timed + args.steps], stamps[first_timed + 1:first_timed + args.steps + 1])]
         out["ms_per_step_first100"], out["ms_per_step_last100"] = round(sum(d[:100]) / 100, 3), round(sum(d[-100:]) / 100, 3)
@@ -165,7 +205,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         log("roofline pass (eager launches bracketed by HIP events)")
         out.update(roofline_pass(model, args, kv_steady[0]))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dense:
         log("cpu baseline (oracle on host cores)")
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args)
     if dist is not None:
@@ -239,7 +279,7 @@ def roofline_pass(model, args, kv_len):
                    for i, l in enumerate(lw)])
     attn_bytes = 2 * (L + 1) * Hkv * D * 2 + (L + 1) * 3 * 4 + 2 * Hq * D * 2 + 2 * Hkv * D * 2
     timed("decode_attn_split_kernel+decode_attn_combine_kernel", NL, NL * n_dec, attn_bytes, 4.0 * (L + 1) * Hq * D,
-          lambda: [o.decode_attn(eng.d_qkv[:qd], c.pool, i, c.slot_of_dev, eng.rope_cs, eng.d_attn, eng.d_ws, Hq, eng.max_len,
+          lambda: [o.decode_attn(eng.d_qkv[:qd], c.pool, i, c.slot_of_dev, eng.rope_cs, eng.d_attn, eng.d_ws, Hq, eng._attn_len,
                                  eng.decode_chunk, scale, length=1, len_dev=kv_dev) for i in range(NL)])
     timed("gemv_bf16_kernel(o_proj)", NL, NL * n_dec, 2 * (H * qd + qd + 2 * H), 2.0 * H * qd,
           lambda: [o.gemv(eng.d_attn, l["o_w"], residual=eng.d_x, out=eng.d_x) for l in lw])

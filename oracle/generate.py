@@ -157,11 +157,15 @@ class StreamCfg:
 
 
 def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
-                   chunk_source: Callable[[int], tuple], keep_logits=False, force_tokens: Optional[List[List[int]]] = None):
+                   chunk_source: Callable[[int], tuple], keep_logits=False, force_tokens: Optional[List[List[int]]] = None,
+                   dense_prefill_chunks: int = 0):
     """The loop of inference.py:309-517 on synthetic inputs.
 
     chunk_source(i) -> (chunk_ids: list[int], pixel_values (N,1176), grid_thw [[t,h,w]])
     Returns dict(ids_per_chunk, new_tokens_per_chunk, kv_len_per_chunk, trace, logits).
+    `dense_prefill_chunks` (build-defined, BASELINE configs[4]): the first N chunks' user turns pile up unanswered and are
+    forwarded in ONE generate() call with the N-th -- all their frames in one forward, as the recompute path of
+    inference.py:423-438 feeds every retained chunk's frames; chunk_source(i, piling=True) omits the assistant header.
     """
     kv = kv_policy.ListKV(cfg.text.num_layers)
     prev_ids: Optional[List[int]] = None
@@ -180,7 +184,17 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
                 kv, prev_ids, _ = kv_policy.sink_window_policy(
                     kv, prev_ids, kv.get_seq_length(), scfg.sink, scfg.window, chunk_trace)
         trace.append(chunk_trace)
-        chunk_ids, pix, grid = chunk_source(i)
+        if dense_prefill_chunks and i < dense_prefill_chunks:
+            chunk_ids, pix, grid = chunk_source(i, piling=i < dense_prefill_chunks - 1)
+            if i == 0:
+                pile_ids, pile_pix, pile_grid = list(chunk_ids), [pix], [list(g) for g in grid]
+            else:
+                pile_ids, pile_pix, pile_grid = pile_ids + list(chunk_ids)[1:], pile_pix + [pix], pile_grid + [list(g) for g in grid]
+            if i < dense_prefill_chunks - 1:
+                continue
+            chunk_ids, pix, grid = pile_ids, torch.cat(pile_pix, 0), pile_grid
+        else:
+            chunk_ids, pix, grid = chunk_source(i)
         # ---- ids = cat(prev, new[skip dup "\n"])  (inference.py:397-406)
         if prev_ids is None:
             ids = list(chunk_ids)
@@ -193,7 +207,7 @@ def streaming_loop(w, cfg: ModelCfg, scfg: StreamCfg, n_chunks: int,
         out = generate(w, cfg, ids, kv, grids, pix, grid, scfg.max_new_tokens, scfg.repetition_penalty,
                        suppress_eos=scfg.suppress_eos, keep_logits=keep_logits, all_text=scfg.all_text,
                        second_per_grid_t=scfg.second_per_grid_t, pos_mode=scfg.pos_mode, sargs=sargs,
-                       force_tokens=None if force_tokens is None else force_tokens[i])
+                       force_tokens=None if force_tokens is None else force_tokens[len(new_tokens)])
         gen = out.sequences
         own_hist.append(out.own)
         generated.append(gen[cur_len:])                                     # without the appended <|im_end|>

@@ -237,7 +237,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
                         generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True, force_tokens=None,
-                        max_len=None, top_k=None, top_p=None):
+                        max_len=None, top_k=None, top_p=None, dense_prefill_chunks=0):
     # The reference synchronises the device around every section to print per-section times.  Nobody reads them when the
     # loop is quiet and not under time_test, and each of the dozen syncs per chunk is host time the GPU spends idle.
     timed_sections = time_test or not quiet
@@ -315,6 +315,15 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
     responses, time_results = [], []
     printq(f"num_chunks: {num_chunks}", quiet=quiet)
 
+    # BASELINE configs[4] ("dense-frame prefill then live decode"): the first `dense_prefill_chunks` chunks are not answered one by
+    # one; their user turns (Time=..s + frames) pile up and go through ONE generate() call with the last of them -- every retained
+    # chunk's frames in one forward, the input shape of the reference's recompute path (inference.py:423-438) and of LiveCC's
+    # multi-frame opening turn (baselines/livecc/demo/infer.py:24-32) -- after which the stream continues chunk by chunk.
+    dense = int(dense_prefill_chunks)
+    if dense and (kv_policy == "structural" or recompute or gt_json is not None):
+        raise ValueError("dense_prefill_chunks works with kv_policy='sink_window' / 'none' on a plain stream")
+    dense_ids, dense_pix, dense_grids = [], [], []
+
     lookahead = None          # (frames, device patches, grid) of the next chunk, fetched one chunk early
     for i in range(num_chunks):
         if chunk_callback is not None:
@@ -359,21 +368,34 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         # ---- prompt + patches
         _sync(); _t = time.perf_counter()
         prompt = f"Time={start_time:.1f}-{start_time + chunk_duration:.1f}s"
+        piling = i < dense - 1                # a dense-prefill turn that is not answered yet: no assistant header behind it
         if i == 0:
             user_content = [{"type": "text", "text": prompt}, {"type": "video", "video": video_path},
                             {"type": "text", "text": query}]
             full_conversation_history = [{"role": "previous text", "content": previous_text},
                                          {"role": "user", "content": user_content}]
-            text = processor.apply_chat_template(full_conversation_history, tokenize=False, add_generation_prompt=True)
+            text = processor.apply_chat_template(full_conversation_history, tokenize=False, add_generation_prompt=not piling)
         else:
             user_content = [{"type": "text", "text": prompt},
                             {"type": "video", "video": video_path, "start": start_time, "duration": chunk_duration}]
             full_conversation_history.append({"role": "user", "content": user_content})
             text = processor.apply_chat_template([{"role": "user", "content": user_content}], tokenize=False,
-                                                 add_generation_prompt=True)
+                                                 add_generation_prompt=not piling)
             text = "\n" + text[SYSTEM_PROMPT_OFFSET:]
         inputs = processor(text=[text], videos=recent_video_window_clips[-1], padding=True, return_tensors="pt")
         new_ids = inputs["input_ids"].cpu()
+        if dense and i < dense:
+            # the turns end with "<|im_end|>\n": drop the leading "\n" of every later one (the rule of inference.py:402-405)
+            dense_ids.append(new_ids if i == 0 else new_ids[:, 1:])
+            dense_pix.append(inputs["pixel_values_videos"].to(device))
+            dense_grids.append(inputs["video_grid_thw"])
+            if piling:
+                section_time["INPUT"] += time.perf_counter() - _t
+                continue
+            new_ids = torch.cat(dense_ids, dim=1)
+            inputs["pixel_values_videos"] = torch.cat(dense_pix, dim=0)
+            inputs["video_grid_thw"] = torch.cat(dense_grids, dim=0)
+            dense_ids, dense_pix, dense_grids = [], [], []
         if prev_generated_ids is not None:
             # the history ends with <|im_end|> (keep the new "\n") or already with "\n" (drop the duplicate)
             if int(prev_generated_ids[0, -1]) != TOKEN_IDS["\n"]:
@@ -395,7 +417,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                 lookahead = None          # the regular path reports the failure when its turn comes
         recent_pixel_values_videos.append(inputs["pixel_values_videos"])
         streaming_args.input_ids = new_ids
-        if i == 0:
+        if streaming_args.video_grid_thw is None:
             streaming_args.video_grid_thw = inputs["video_grid_thw"]
         else:
             streaming_args.video_grid_thw = torch.cat([streaming_args.video_grid_thw, inputs["video_grid_thw"]], dim=0)
@@ -414,7 +436,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         if top_p is not None:
             gen_kw["top_p"] = top_p
         if force_tokens is not None:          # parity tests: per-chunk teacher forcing (engine.generate)
-            gen_kw["force_tokens"] = force_tokens[i]
+            gen_kw["force_tokens"] = force_tokens[len(responses)]          # one entry per ANSWERED chunk
         if recompute:
             if past_key_values is not None:
                 past_key_values.release_reserved()

@@ -262,9 +262,12 @@ class SvlmEngine:
         self.max_len = int(max_len)
         self.max_new = int(max_new_tokens)
         self.kv_slack, self.kv_page_tokens = float(kv_slack), int(kv_page_tokens)      # KV pool head-room over max_len, page size
-        if decode_chunk is None:
-            decode_chunk = self.pick_decode_chunk(self.max_len, tc.num_kv_heads)
-        self.decode_chunk = int(os.environ.get("SVLM_DECODE_CHUNK", decode_chunk))
+        # keys per decode-attention workgroup: fixed when given (or SVLM_DECODE_CHUNK), else picked per generate() call from the
+        # CURRENT sequence length -- an engine sized for a 90k-row dense prefill decodes its 4k-row live window with the
+        # bounded-window geometry, not with the long-cache one
+        self._fixed_chunk = decode_chunk if decode_chunk is not None else (int(os.environ["SVLM_DECODE_CHUNK"]) if "SVLM_DECODE_CHUNK" in os.environ else None)
+        self.decode_chunk = int(self._fixed_chunk if self._fixed_chunk is not None else self.pick_decode_chunk(self.max_len, tc.num_kv_heads))
+        self._attn_len = self.max_len          # bound on the sequence length the current call's decode attention covers
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
         dev = self.device
         H, V = tc.hidden_size, tc.vocab_size
@@ -292,13 +295,14 @@ class SvlmEngine:
         self.d_attn = torch.zeros(self.qd, dtype=BF16, device=dev)
         self.d_gu = torch.zeros(2 * tc.intermediate_size, dtype=BF16, device=dev)
         self.d_h = torch.zeros(tc.intermediate_size, dtype=BF16, device=dev)
-        self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, self.decode_chunk, dev)
+        self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, 16 if self._fixed_chunk is None else self.decode_chunk, dev)
         self.d_sws = ops.sampling_ws(V, dev)
         self._vit_rope_cache = {}
         self._vis_stream = None            # side stream the NEXT chunk's ViT runs on while this chunk decodes
         self._vis_pending = None           # [pixel tensor, grid, event, features, unfinished _VitRun]
         # ViT blocks of a look-ahead pass held back for the gap between chunks (~0.19 ms each at 448x448 on the 2B tower)
         self.vit_tail = int(os.environ.get("SVLM_VIT_TAIL", 5))
+        self.section_events = None         # bench: [] -> generate() appends (name, start event, end event) of its ViT / prefill phases
         self._graph = None
         self._graph_key = None
         self._penalty = 1.0
@@ -362,11 +366,29 @@ class SvlmEngine:
                                              win_runs=_runs(win_len), full_runs=_runs(frame_len))
         return self._vit_rope_cache[key]
 
+    VIT_BATCH_SEQS = 8            # attention sequences (frames' temporal grids) per ViT pass of a many-frame call
+
     def vision_forward(self, pixel_values, grid_thw):
-        """streaming_visual_encoder_forward: (N, C*T*P*P) patches -> (N / merge^2, hidden)."""
-        run = _VitRun(self, pixel_values, grid_thw)
-        run.blocks(0, self.cfg.vision.depth)
-        return run.finish()
+        """streaming_visual_encoder_forward: (N, C*T*P*P) patches -> (N / merge^2, hidden).  A call with many grids (dense-frame
+        prefill, recompute) runs in passes of VIT_BATCH_SEQS sequences: the GEMMs see 8k rows instead of 1k, the activations of
+        600 frames never exist at once."""
+        grid = [[int(v) for v in g] for g in (grid_thw.tolist() if hasattr(grid_thw, "tolist") else grid_thw)]
+        if sum(g[0] for g in grid) <= self.VIT_BATCH_SEQS or len({g[1] * g[2] for g in grid}) != 1:
+            run = _VitRun(self, pixel_values, grid)
+            run.blocks(0, self.cfg.vision.depth)
+            return run.finish()
+        outs, row, i = [], 0, 0
+        while i < len(grid):
+            j, seqs = i, 0
+            while j < len(grid) and (seqs == 0 or seqs + grid[j][0] <= self.VIT_BATCH_SEQS):
+                seqs += grid[j][0]
+                j += 1
+            n = sum(t * h * w for t, h, w in grid[i:j])
+            run = _VitRun(self, pixel_values[row:row + n], grid[i:j])
+            run.blocks(0, self.cfg.vision.depth)
+            outs.append(run.finish())
+            row, i = row + n, j
+        return torch.cat(outs, 0)
 
     def vision_prefetch(self, pixel_values, grid_thw):
         """Enqueue the ViT + merger of the NEXT chunk's frames.  Frames do not depend on generated text, so most of the
@@ -433,7 +455,10 @@ class SvlmEngine:
         return self.vision_forward(pixel_values, grid_thw)
 
     # ------------------------------------------------------------------ LLM
-    def _prefill(self, c: KVPool, idx_dev, vis, T: int, L_before: int):
+    PREFILL_ROWS = 4096           # rows per pass of a long prefill (dense-frame prompts are tens of thousands of rows)
+
+    def _prefill(self, c: KVPool, idx_dev, vis, T: int, L_before: int, head: bool = True):
+        """Rows L_before .. L_before+T-1 through all layers (their K/V rows go to the pool); `head`: last-row logits."""
         o, w, tc = self.ops, self.w, self.cfg.text
         H, qd, kd = tc.hidden_size, self.qd, self.kd
         L = L_before + T
@@ -464,6 +489,8 @@ class SvlmEngine:
                 o.gemm_norm(hm, lw["down_w"], w.layers[li + 1]["ln1"], tc.rms_eps, x, xn, residual=x)
             else:
                 o.gemm(hm, lw["down_w"], residual=x, out=x)
+        if not head:
+            return
         last = x[T - 1:T].contiguous()
         o.rmsnorm(last, w.final_norm, tc.rms_eps, out=self.d_xn.view(1, H))
         o.gemv(self.d_xn, w.lm_head, out_f32=self.logits)
@@ -480,7 +507,7 @@ class SvlmEngine:
             o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
                       len_dev=kv_len)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
-                          self.max_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
+                          self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
             o.dec_gate_up(self.d_x, lw["ln2"], tc.rms_eps, lw["gu_w"], self.d_h)
             o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)
@@ -510,7 +537,7 @@ class SvlmEngine:
             self._decode_step_launch(c)
             self._sample_launch(1, fused=True)
             return
-        key = (id(c), self._penalty, self._suppress is not None, self._sampling)
+        key = (id(c), self._penalty, self._suppress is not None, self._sampling, self.decode_chunk, self._attn_len)
         if self._graph is None or self._graph_key != key:
             # capture once per (cache, sampling config); state is restored because capture does not execute
             g = torch.cuda.CUDAGraph()
@@ -519,6 +546,16 @@ class SvlmEngine:
                 self._sample_launch(1, fused=True)
             self._graph, self._graph_key = g, key
         self._graph.replay()
+
+    def _mark(self, name=None, start=None):
+        """Section timing for bench.py (off unless `section_events` is a list): an event now; with `name`, the (start, now) pair."""
+        if self.section_events is None or self.device.type != "cuda":
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if name is not None:
+            self.section_events.append((name, start, ev))
+        return ev
 
     # ------------------------------------------------------------------ generate
     def generate(self, ids: Sequence[int], cache: Optional[KVPool], video_grid_thw, pixel_values=None, grid_thw=None,
@@ -547,6 +584,11 @@ class SvlmEngine:
         if L_ids + max_new_tokens > self.max_len:
             raise MemoryError(f"sequence {L_ids}+{max_new_tokens} exceeds engine max_len {self.max_len}")
         dev = self.device
+        if self._fixed_chunk is None:
+            # decode-attention geometry of THIS call: split size from the current length, grid bounded by it (rounded up to 1k rows
+            # so that a steady stream keeps one captured graph)
+            self.decode_chunk = self.pick_decode_chunk(L_ids + max_new_tokens, tc.num_kv_heads)
+            self._attn_len = min(self.max_len, -(-(L_ids + max_new_tokens) // 1024) * 1024)
         # ---- shrink-mode positions for the whole (pruned) sequence + the tokens to be generated
         n_rows = L_ids + max_new_tokens
         is_f = cfg.family == "qwen2_5" and not all_text
@@ -596,7 +638,9 @@ class SvlmEngine:
         if vmask.any():
             if pixel_values is None:
                 raise ValueError("video tokens in the un-cached suffix but no pixel_values_videos")
+            ev0 = self._mark()
             vis = self._vision(pixel_values, grid_thw)
+            self._mark("vit", ev0)
             n_tok = int(vmask.sum())
             if n_tok != vis.shape[0]:
                 raise ValueError(f"Video features and video tokens do not match: tokens: {n_tok}, features {vis.shape[0]}")
@@ -633,7 +677,13 @@ class SvlmEngine:
                 self._sample_calls += 1
                 self.rng_dev.copy_(torch.from_numpy(np.array([z & 0xFFFFFFFF, z >> 32], dtype=np.uint32).view(np.int32)))
 
-        self._prefill(cache, idx_dev, vis, T, L_before)
+        # a prompt of tens of thousands of rows (dense-frame prefill) goes through in passes: causal attention over the rows
+        # already in the pool makes the passes arithmetically the same forward
+        ev0 = self._mark()
+        for t0 in range(0, T, self.PREFILL_ROWS):
+            tc_rows = min(self.PREFILL_ROWS, T - t0)
+            self._prefill(cache, idx_dev[t0:t0 + tc_rows], vis, tc_rows, L_before + t0, head=t0 + tc_rows == T)
+        self._mark("prefill", ev0)
         if keep_logits:
             logits_out.append(self.logits.detach().cpu().clone())
         self._sample_launch(0)

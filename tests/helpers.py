@@ -23,7 +23,7 @@ def oracle_cfg(cfg: C.ModelConfig) -> om.ModelCfg:
 
 def chunk_source(proc, video, previous_text="", query="Commentate on this match", chunk_duration=1, skip_first_chunk=0):
     """Per-chunk (ids, pixel_values, grid) exactly as streaming_inference builds them (inference.py:351-395)."""
-    def src(i):
+    def src(i, piling=False):
         start = (i + skip_first_chunk) * chunk_duration
         prompt = f"Time={start:.1f}-{start + chunk_duration:.1f}s"
         frames = video.chunk(start, chunk_duration)
@@ -31,22 +31,22 @@ def chunk_source(proc, video, previous_text="", query="Commentate on this match"
             conv = [{"role": "previous text", "content": previous_text},
                     {"role": "user", "content": [{"type": "text", "text": prompt}, {"type": "video", "video": ""},
                                                  {"type": "text", "text": query}]}]
-            text = proc.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)
+            text = proc.apply_chat_template(conv, tokenize=False, add_generation_prompt=not piling)
         else:
             conv = [{"role": "user", "content": [{"type": "text", "text": prompt}, {"type": "video", "video": ""}]}]
-            text = "\n" + proc.apply_chat_template(conv, tokenize=False, add_generation_prompt=True)[S.SYSTEM_PROMPT_OFFSET:]
+            text = "\n" + proc.apply_chat_template(conv, tokenize=False, add_generation_prompt=not piling)[S.SYSTEM_PROMPT_OFFSET:]
         out = proc(text=[text], videos=frames, return_tensors="pt")
         return out["input_ids"][0].tolist(), out["pixel_values_videos"], out["video_grid_thw"].tolist()
     return src
 
 
 def run_oracle_stream(cfg, sd, n_chunks, size=56, fps=1.0, policy="sink_window", sink=4, window=64, max_new=8, suppress_eos=True,
-                      previous_text="hello world", keep_logits=False, force_tokens=None, **policy_kw):
+                      previous_text="hello world", keep_logits=False, force_tokens=None, dense_prefill_chunks=0, **policy_kw):
     proc = S.SyntheticProcessor()
     video = S.SyntheticVideo(size, fps, 0)
     scfg = og.StreamCfg(policy=policy, sink=sink, window=window, max_new_tokens=max_new, suppress_eos=suppress_eos, **policy_kw)
     return og.streaming_loop(sd, oracle_cfg(cfg), scfg, n_chunks, chunk_source(proc, video, previous_text), keep_logits=keep_logits,
-                             force_tokens=force_tokens)
+                             force_tokens=force_tokens, dense_prefill_chunks=dense_prefill_chunks)
 
 
 def decisive_offset(size=56, max_new=8, all_text=False):

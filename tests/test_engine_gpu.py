@@ -149,6 +149,16 @@ def test_tiny_stream_iid_weights_teacher_forced():
     assert out["same"] >= 0.9 * out["steps"], out
 
 
+def test_dense_prefill_then_live_stream():
+    """BASELINE configs[4] shape: 6 chunks of frames piled into ONE forward (ViT in passes of 2 grids, LLM prefill in passes of 48 rows,
+    both forced small here), then live chunks under sink/window eviction -- same bars as every other stream, bf16 and fp8-free."""
+    cfg, sd, model = _tiny_model()
+    eng = model._svlm_engine
+    eng.PREFILL_ROWS, eng.VIT_BATCH_SEQS = 48, 2
+    out = _compare(cfg, sd, 10, model, window=96, dense_prefill_chunks=6)
+    assert out["steps"] == 5 * 8
+
+
 def test_tiny_stream_structural():
     cfg, sd, model = _tiny_model()
     _compare(cfg, sd, 8, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,

@@ -364,3 +364,23 @@ def test_sampling_with_top_k_1_is_greedy_in_oracle_and_engine(tiny):
     S.streaming_inference(model=_model(cfg, sd), do_sample=True, temperature=0.9, top_k=1, ids_log=a, **kw)
     S.streaming_inference(model=_model(cfg, sd), do_sample=False, ids_log=b, **kw)
     assert [e["new"] for e in a] == [e["new"] for e in b]
+
+
+def test_dense_prefill_chunks_equal_one_forward_of_the_piled_turns(tiny):
+    """BASELINE configs[4] shape on the CPU backend: 5 chunks piled into one generate() call (ViT in passes, prefill in passes of
+    PREFILL_ROWS), then live chunks with sink/window eviction -- tokens, KV lengths and eviction trace equal the oracle's, whose
+    piled forward is one plain pass."""
+    cfg, sd = tiny
+    sd = H.decisive_weights(cfg)
+    model = _model(cfg, sd)
+    eng = model._svlm_engine
+    eng.PREFILL_ROWS, eng.VIT_BATCH_SEQS = 32, 2                 # force several passes on the tiny stream
+    kw = dict(window=64, dense_prefill_chunks=5)
+    res, trace, counts, log = H.run_engine_stream(model, 9, **kw)
+    ref = H.run_oracle_stream(cfg, sd, 9, **kw)
+    assert len(res) == 5 and len(log) == 5                      # chunks 4 .. 8 answer; 0 .. 3 only pile up
+    live = [t for t in ref["trace"] if True]
+    assert [e["new"] for e in log] == ref["new_tokens"]
+    assert [e["kv_len"] for e in log] == ref["kv_len"]
+    assert [t for t in trace if t] == [t for t in live if t] and any(t for t in trace)
+    assert log[0]["ids"].count(151652) == 5                     # five vision spans in the first answered sequence
