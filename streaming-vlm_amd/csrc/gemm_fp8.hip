@@ -84,19 +84,24 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned char* __re
     const unsigned char* sa = smem + stage * STAGE_B;
     const unsigned char* sw = sa + BM * 128;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      // lane (fr, fq) holds k = 32 ks + 8 fq .. + 7 of row fr: byte 32 ks + 8 fq -> 16-B chunk 2 ks + (fq >> 1), half fq & 1
-      long af[TM], wf[4];
-      const int pos = (((ks * 2 + (fq >> 1)) ^ (fr & 7)) * 16) + (fq & 1) * 8;
+    for (int j = 0; j < 2; ++j) {
+      // A dot product does not care in which order k is walked as long as both operands walk it alike: lane (fr, fq) takes the
+      // 16-B chunk 4 j + fq of its row with ONE ds_read_b128 (the bank-conflict-free swizzle of the bf16 kernel) and feeds its low
+      // 8 bytes to MFMA k-step 2 j and its high 8 bytes to k-step 2 j + 1 -- the four lane groups still cover disjoint k ranges.
+      typedef long l2_t __attribute__((ext_vector_type(2)));
+      l2_t af[TM], wf[4];
+      const int pos = ((4 * j + fq) ^ (fr & 7)) * 16;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const long*>(sa + (wm * 16 * TM + i * 16 + fr) * 128 + pos);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const l2_t*>(sa + (wm * 16 * TM + i * 16 + fr) * 128 + pos);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const long*>(sw + (wn * 64 + j * 16 + fr) * 128 + pos);
+      for (int jj = 0; jj < 4; ++jj) wf[jj] = *reinterpret_cast<const l2_t*>(sw + (wn * 64 + jj * 16 + fr) * 128 + pos);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[jj][h], af[i][h], acc[i][jj], 0, 0, 0);
     }
   };
   constexpr int AHEAD = NS - 1;
@@ -204,10 +209,11 @@ extern "C" int svlm_gemm_fp8(const void* A8, int lda, const float* a_scale, cons
   if (M == 0) return SVLM_OK;
   hipStream_t st = (hipStream_t)stream;
   const int gn = (N + F8_BN - 1) / F8_BN;
-  // plan: 128-row tiles once they alone fill the chip, else 64-row tiles; split K when the tile grid is still below ~one round of the
-  // 256 CUs (ViT proj / fc2 at one frame: N = 1280) -- the same reasoning as gemm.hip's cost model, with half its K-steps
-  int bm = ((long long)((M + 127) / 128) * gn >= 200) ? 128 : 64;
-  if (M <= 64) bm = 64;
+  // plan: 64-row tiles -- 72 KB of LDS, so TWO workgroups share a CU and one's DMA wait hides under the other's MFMAs; measured on
+  // MI355X (tools/gemm_fp8_vs_bf16.py, ViT shapes): 64-row tiles 559 / 733 TFLOP/s on qkv at M = 1024 / 8192 where 128-row tiles
+  // (96 KB, one workgroup per CU) reach 416 / 507 and the bf16 kernel 466 / 551.  Split K when the tile grid is still below ~one
+  // round of the 256 CUs (ViT proj / fc2 at one frame: N = 1280).
+  int bm = 64;
   int splits = 1;
   const long long tiles = (long long)((M + bm - 1) / bm) * gn;
   if (ws != nullptr && tiles < 160 && K >= 1024) {

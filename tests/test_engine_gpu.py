@@ -37,6 +37,7 @@ def _compare(cfg, sd, n_chunks, model, floor=True, truth=True, exact_tokens=True
     force = ref["generated"]
     _, trace, counts, ids_log = H.run_engine_stream(model, n_chunks, keep_logits=True, force_tokens=force, **kw)
     assert trace == ref["trace"], f"eviction indices differ:\n{trace}\n{ref['trace']}"
+    n_stream, n_chunks = n_chunks, len(force)          # answered chunks (a dense prefill piles the first ones into one answer)
     for i in range(n_chunks):
         assert ids_log[i]["kv_len"] == ref["kv_len"][i], (i, ids_log[i]["kv_len"], ref["kv_len"][i])
         assert len(ids_log[i]["logits"]) == len(ref["logits"][i]) == len(force[i])
@@ -67,7 +68,7 @@ def _compare(cfg, sd, n_chunks, model, floor=True, truth=True, exact_tokens=True
     # ---- (a) fp32 truth
     if truth:
         sd32 = {k: v.float() for k, v in sd.items()}
-        tru = H.run_oracle_stream(cfg, sd32, n_chunks, keep_logits=True, force_tokens=force, **kw)
+        tru = H.run_oracle_stream(cfg, sd32, n_stream, keep_logits=True, force_tokens=force, **kw)
         assert tru["trace"] == ref["trace"]
         hip_sum = ora_sum = worst_ratio = 0.0
         for i in range(n_chunks):
@@ -83,7 +84,7 @@ def _compare(cfg, sd, n_chunks, model, floor=True, truth=True, exact_tokens=True
     if floor:
         om.ATTN_TILE = 32
         try:
-            alt = H.run_oracle_stream(cfg, sd, n_chunks, keep_logits=True, force_tokens=force, **kw)
+            alt = H.run_oracle_stream(cfg, sd, n_stream, keep_logits=True, force_tokens=force, **kw)
         finally:
             om.ATTN_TILE = None
         fmax = fmean = 0.0
