@@ -130,72 +130,127 @@ __device__ __forceinline__ unsigned sf_key(float x) {        // order-preserving
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Walk the processed scores of the whole vocabulary once: 16 elements per thread and step (four 16-B loads of logits and four
+// 4-B loads of `seen` issued before anything is consumed -- a one-workgroup scan is latency-bound otherwise: 150 dependent
+// round trips per thread cost 50+ us per pass), fn(v, score) per element.
+// SUP = false leaves the (at most 8) suppressed ids in: a caller that only COUNTS may prefer to correct for them afterwards
+// instead of paying 8 compares on each of 150k elements (the scan runs on one CU and is VALU-bound).
+template <bool SUP = true, typename F>
+__device__ __forceinline__ void sf_scan(const float* __restrict__ logits, const unsigned char* __restrict__ seen, int V, float penalty,
+                                        const int (&sup)[8], float inv_temp, F&& fn) {
+  const int tid = threadIdx.x;
+  auto one = [&](int v, float x, unsigned char sn) {
+    if (sn) x = x < 0.f ? x * penalty : x / penalty;
+    if constexpr (SUP) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (sup[s] == v) x = -INFINITY;
+    }
+    fn(v, x * inv_temp);
+  };
+  const int V4 = (V % 4 == 0) ? V / 4 : 0;             // vector path needs 16-B aligned rows of 4
+  for (int base = 0; base < V4; base += 4 * SF_THREADS) {
+    f32x4_t lx[4];
+    unsigned ls[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = min(base + u * SF_THREADS + tid, V4 - 1);
+      lx[u] = *reinterpret_cast<const f32x4_t*>(logits + 4 * q);
+      ls[u] = seen ? *reinterpret_cast<const unsigned*>(seen + 4 * q) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = base + u * SF_THREADS + tid;
+      if (q < V4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) one(4 * q + e, lx[u][e], (unsigned char)(ls[u] >> (8 * e)));
+      }
+    }
+  }
+  for (int v = 4 * V4 + tid; v < V; v += SF_THREADS) one(v, logits[v], seen ? seen[v] : (unsigned char)0);
+}
+
+#define SF_BINS 2048        // top 11 bits of the order-preserving key: sign, exponent, 2 mantissa bits (quarter-octave bins)
+
 __global__ __launch_bounds__(SF_THREADS) void sample_filtered_kernel(const float* __restrict__ logits, int V,
                                                                      const unsigned char* __restrict__ seen, float penalty,
                                                                      const int* __restrict__ suppress, int n_suppress, float inv_temp,
                                                                      int top_k, float top_p, const unsigned* __restrict__ rng,
                                                                      unsigned char* seen_w, int* tok_buf, int* state, int advance_kv) {
-  __shared__ unsigned hist[256];
+  __shared__ unsigned hist[SF_BINS];
   __shared__ unsigned long long cand[SF_CAP];          // (key << 32) | ~index : sorts by score, then lowest index first
   __shared__ float fsum[SF_CAP];
-  __shared__ unsigned sh_prefix, sh_want, sh_n;
+  __shared__ unsigned sh_bin, sh_n, sh_above, sh_done;
   const int tid = threadIdx.x;
   int sup[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) sup[s] = s < n_suppress ? suppress[s] : -1;
-  auto score = [&](int v) -> float {
-    float x = logits[v];
-    if (seen && seen[v]) x = x < 0.f ? x * penalty : x / penalty;
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-      if (sup[s] == v) x = -INFINITY;
-    return x * inv_temp;
-  };
   const int k_eff = min(top_k, V);
-  // ---- radix select: the k_eff-th largest key, 8 bits per pass
-  if (tid == 0) { sh_prefix = 0u; sh_want = (unsigned)k_eff; }
+  // ---- radix descent, 11 bits per level (normally ONE level): the narrowest key range [lo_key, inf) that still holds the k largest
+  // scores and fits the candidate list
+  if (tid == 0) { sh_n = 0u; sh_bin = 0u; sh_above = 0u; sh_done = 0u; }
   __syncthreads();
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    if (tid < 256) hist[tid] = 0u;
+  unsigned prefix = 0u;                                // exact high bits of the threshold key found so far
+  for (int level = 0; level < 3; ++level) {
+    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+    const unsigned dmask = level == 2 ? 1023u : 2047u;
+    const unsigned hmask = level == 0 ? 0u : (0xFFFFFFFFu << (level == 1 ? 21 : 10));
+    for (int i = tid; i < SF_BINS; i += SF_THREADS) hist[i] = 0u;
     __syncthreads();
-    const unsigned prefix = sh_prefix;
-    const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-    for (int v = tid; v < V; v += SF_THREADS) {
-      const unsigned key = sf_key(score(v));
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    // (suppressed ids are counted here as if they were alive and asked for on top of k below: the range found is at most
+    // n_suppress ranks too wide, and the collect pass drops them)
+    sf_scan<false>(logits, seen, V, penalty, sup, inv_temp, [&](int, float sc) {
+      const unsigned key = sf_key(sc);
+      if ((key & hmask) == prefix) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+    });
+    __syncthreads();
+    for (int off = 1; off < SF_BINS; off <<= 1) {     // suffix counts: hist[d] <- keys of this level with digit >= d
+      unsigned a0 = 0u, a1 = 0u;
+      const int i0 = tid, i1 = tid + SF_THREADS;
+      if (i0 + off < SF_BINS) a0 = hist[i0 + off];
+      if (i1 + off < SF_BINS) a1 = hist[i1 + off];
+      __syncthreads();
+      hist[i0] += a0; hist[i1] += a1;
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned want = sh_want, b = 255u;
-      for (;; --b) {                                   // walk the bins from the largest digit down
-        if (hist[b] >= want || b == 0u) break;
-        want -= hist[b];
+    const unsigned above = sh_above;                   // keys strictly above the range this level splits
+    const unsigned k_cnt = (unsigned)min(k_eff + n_suppress, V);
+    const unsigned want = k_cnt > above ? k_cnt - above : 1u;
+    for (int i = tid; i < SF_BINS; i += SF_THREADS) {
+      const unsigned nxt = i + 1 < SF_BINS ? hist[i + 1] : 0u;
+      if (hist[i] >= want && nxt < want) {             // the digit whose bin holds the k-th largest (suffix counts fall with the digit)
+        sh_bin = (unsigned)i;
+        sh_above = above + nxt;
+        sh_done = (above + hist[i] <= (unsigned)SF_CAP || level == 2) ? 1u : 0u;
       }
-      sh_prefix = prefix | (b << shift);
-      sh_want = want;
     }
     __syncthreads();
+    prefix |= sh_bin << shift;
+    if (sh_done) break;
   }
-  const unsigned tau = sh_prefix;                      // key of the k_eff-th largest score
-  // ---- survivors: every score >= the threshold (ties kept, like HF), capped at SF_CAP
-  if (tid == 0) sh_n = 0u;
-  __syncthreads();
-  for (int v = tid; v < V; v += SF_THREADS) {
-    const unsigned key = sf_key(score(v));
-    if (key >= tau && key > sf_key(-INFINITY)) {
+  const unsigned lo_key = prefix;
+  // ---- collect: every key >= lo_key goes to the list (the k largest are among them); -inf never does
+  sf_scan<false>(logits, seen, V, penalty, sup, inv_temp, [&](int v, float sc) {
+    const unsigned key = sf_key(sc);
+    if (key >= lo_key && sc > -INFINITY) {
+      bool dead = false;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) dead |= sup[s] == v;
+      if (dead) return;
       const unsigned slot = atomicAdd(&sh_n, 1u);
       if (slot < SF_CAP) cand[slot] = ((unsigned long long)key << 32) | (unsigned)(~(unsigned)v);
     }
-  }
+  });
   __syncthreads();
-  const int n = (int)min(sh_n, (unsigned)SF_CAP);
-  for (int i = n + tid; i < SF_CAP; i += SF_THREADS) cand[i] = 0ull;
+  const int n_list = (int)min(sh_n, (unsigned)SF_CAP);
+  int P = 64;                                          // sort size: next power of two
+  while (P < n_list) P <<= 1;
+  for (int i = n_list + tid; i < P; i += SF_THREADS) cand[i] = 0ull;
   __syncthreads();
   // ---- bitonic sort, descending
-  for (int k = 2; k <= SF_CAP; k <<= 1) {
+  for (int k = 2; k <= P; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < SF_CAP; i += SF_THREADS) {
+      for (int i = tid; i < P; i += SF_THREADS) {
         const int ixj = i ^ j;
         if (ixj > i) {
           const unsigned long long a = cand[i], b = cand[ixj];
@@ -206,22 +261,28 @@ __global__ __launch_bounds__(SF_THREADS) void sample_filtered_kernel(const float
       __syncthreads();
     }
   }
+  // ---- top-k: the k largest plus every tie of the k-th (HF keeps all scores >= the k-th largest)
+  int n = min(k_eff, n_list);
+  if (n > 0) {
+    const unsigned kth = (unsigned)(cand[n - 1] >> 32);
+    while (n < n_list && (unsigned)(cand[n] >> 32) == kth) ++n;
+  }
   // ---- softmax weights over the survivors, e_i = exp(s_i - s_0)
   auto key_score = [](unsigned key) -> float {
     const unsigned u = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
     return __uint_as_float(u);
   };
   const float s0 = n > 0 ? key_score((unsigned)(cand[0] >> 32)) : 0.f;
-  for (int i = tid; i < SF_CAP; i += SF_THREADS) fsum[i] = i < n ? __expf(key_score((unsigned)(cand[i] >> 32)) - s0) : 0.f;
+  for (int i = tid; i < P; i += SF_THREADS) fsum[i] = i < n ? __expf(key_score((unsigned)(cand[i] >> 32)) - s0) : 0.f;
   __syncthreads();
-  // inclusive prefix sums (Hillis-Steele over 2048 entries, two per thread)
-  for (int off = 1; off < SF_CAP; off <<= 1) {
+  for (int off = 1; off < P; off <<= 1) {              // inclusive prefix sums
     float a0 = 0.f, a1 = 0.f;
     const int i0 = tid, i1 = tid + SF_THREADS;
-    if (i0 >= off) a0 = fsum[i0 - off];
-    if (i1 >= off) a1 = fsum[i1 - off];
+    if (i0 < P && i0 >= off) a0 = fsum[i0 - off];
+    if (i1 < P && i1 >= off) a1 = fsum[i1 - off];
     __syncthreads();
-    fsum[i0] += a0; fsum[i1] += a1;
+    if (i0 < P) fsum[i0] += a0;
+    if (i1 < P) fsum[i1] += a1;
     __syncthreads();
   }
   if (tid == 0) {
@@ -276,17 +337,9 @@ __global__ __launch_bounds__(SF_THREADS) void sample_nucleus_kernel(const float*
   int sup[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) sup[s] = s < n_suppress ? suppress[s] : -1;
-  auto score = [&](int v) -> float {
-    float x = logits[v];
-    if (seen && seen[v]) x = x < 0.f ? x * penalty : x / penalty;
-#pragma unroll
-    for (int s = 0; s < 8; ++s)
-      if (sup[s] == v) x = -INFINITY;
-    return x * inv_temp;
-  };
   // ---- max score (for exp) ...
   float mx = -INFINITY;
-  for (int v = tid; v < V; v += SF_THREADS) mx = fmaxf(mx, score(v));
+  sf_scan(logits, seen, V, penalty, sup, inv_temp, [&](int, float sc) { mx = fmaxf(mx, sc); });
   mx = wave_max(mx);
   if ((tid & 63) == 0) red_f[tid >> 6] = mx;
   __syncthreads();
@@ -308,10 +361,10 @@ __global__ __launch_bounds__(SF_THREADS) void sample_nucleus_kernel(const float*
       __syncthreads();
       const unsigned prefix = sh_prefix;
       const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-      for (int v = tid; v < V; v += SF_THREADS) {
-        const unsigned key = sf_key(score(v));
+      sf_scan(logits, seen, V, penalty, sup, inv_temp, [&](int, float sc) {
+        const unsigned key = sf_key(sc);
         if ((key & mask) == prefix) atomicAdd(&cnt[(key >> shift) & 255u], 1u);
-      }
+      });
       __syncthreads();
       if (tid == 0) {
         unsigned want = sh_want, b = 255u;
@@ -336,14 +389,13 @@ __global__ __launch_bounds__(SF_THREADS) void sample_nucleus_kernel(const float*
       __syncthreads();
       const unsigned prefix = sh_prefix;
       const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-      for (int v = tid; v < V; v += SF_THREADS) {
-        const float sc = score(v);
+      sf_scan(logits, seen, V, penalty, sup, inv_temp, [&](int, float sc) {
         const unsigned key = sf_key(sc);
         if (key >= tau && (key & mask) == prefix) {
           const unsigned long long m = (unsigned long long)(__expf(sc - smax) * 1099511627776.0f);        // 2^40 fixed point
           if (m) atomicAdd(&mass[(key >> shift) & 255u], m);
         }
-      }
+      });
       __syncthreads();
       if (tid == 0) {
         if (pass == 0) {
@@ -368,10 +420,9 @@ __global__ __launch_bounds__(SF_THREADS) void sample_nucleus_kernel(const float*
   const unsigned step = (unsigned)(state[1] + 1);
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int v = tid; v < V; v += SF_THREADS) {
-    const float sc = score(v);
+  sf_scan(logits, seen, V, penalty, sup, inv_temp, [&](int v, float sc) {
     if (sf_key(sc) >= tau && sc > -INFINITY) am_better(best, bi, sc + svlm_gumbel_noise(rng, step, (unsigned)v), v);
-  }
+  });
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ob = __shfl_xor(best, o, 64);
