@@ -382,20 +382,18 @@ def roofline_pass(model, args, kv_len):
              "roofline_decode_attn": {"bound": "hbm", "achieved": da["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(da["GBps"] / HBM_PEAK_GBS, 4), "avg_launch_us": da["avg_us"],
                                       "algorithmic_bytes_per_launch": da["bytes_per_launch"], "kv_len": L + 1}}
-    # long-window point (mode (a) "full attention" regime): the same kernel where it is genuinely bandwidth-bound
-    try:
-        Lbig = 32768
-        eng2_len = Lbig + 64
-        pool = torch.zeros((1, 2, Hkv, eng2_len, D), dtype=torch.bfloat16, device=dev)
-        slot = torch.arange(eng2_len, dtype=torch.int32, device=dev)
-        rope = torch.zeros((eng2_len, D), dtype=torch.bfloat16, device=dev)
-        ch = type(eng).pick_decode_chunk(eng2_len, Hkv)
-        ws = o.decode_attn_ws(Hq, eng2_len, ch, dev)
-        out = torch.empty(qd, dtype=torch.bfloat16, device=dev)
-        qq = torch.randn(qd, device=dev).to(torch.bfloat16)
-        # 8 different pools (cold K/V, 270 MB in all) replayed from one graph: per-launch time without event overhead
-        pools = [pool] + [torch.zeros_like(pool) for _ in range(7)]
-        fn = lambda: [o.decode_attn(qq, p, 0, slot, rope, out, ws, Hq, eng2_len, ch, scale, length=Lbig) for p in pools]
+    # long-window points (mode (a) "full attention" regime), where the kernel is bandwidth-bound: this model's head geometry and the
+    # 7B's (28 query / 4 kv heads) at 32k and 131k keys; split + combine, 8 different cold pools replayed from one graph
+    def long_point(hq, hkv, Lbig):
+        cap = Lbig + 64
+        slot = torch.arange(cap, dtype=torch.int32, device=dev)
+        rope = torch.zeros((cap, D), dtype=torch.bfloat16, device=dev)
+        ch = type(eng).pick_decode_chunk(cap, hkv)
+        ws = o.decode_attn_ws(hq, cap, ch, dev)
+        out = torch.empty(hq * D, dtype=torch.bfloat16, device=dev)
+        qq = torch.randn(hq * D, device=dev).to(torch.bfloat16)
+        pools = [(torch.randn((1, 2, hkv, cap, D), device=dev) * 0.5).to(torch.bfloat16) for _ in range(8)]
+        fn = lambda: [o.decode_attn(qq, p, 0, slot, rope, out, ws, hq, cap, ch, scale, length=Lbig) for p in pools]
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -411,10 +409,16 @@ def roofline_pass(model, args, kv_len):
             torch.cuda.synchronize()
             t = s.elapsed_time(e) / len(pools)
             best = t if best is None else min(best, t)
-        nb = 2 * Lbig * Hkv * D * 2 + Lbig * 3 * 4
-        extra["roofline_decode_attn_32k"] = {"kv_len": Lbig, "keys_per_workgroup": ch, "avg_launch_us": round(best * 1e3, 2), "achieved": round(nb / best / 1e6, 1),
-                                             "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(nb / best / 1e6 / HBM_PEAK_GBS, 4),
-                                             "algorithmic_bytes_per_launch": nb}
+        nb = 2 * Lbig * hkv * D * 2 + Lbig * 3 * 4
+        return {"kv_len": Lbig, "q_heads": hq, "kv_heads": hkv, "keys_per_workgroup": ch, "avg_launch_us": round(best * 1e3, 2),
+                "achieved": round(nb / best / 1e6, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(nb / best / 1e6 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": nb}
+    try:
+        extra["roofline_decode_attn_32k"] = long_point(Hq, Hkv, 32768)
+        pts = [long_point(Hq, Hkv, 131072)]
+        if (Hq, Hkv) != (28, 4):
+            pts += [long_point(28, 4, 32768), long_point(28, 4, 131072)]
+        extra["roofline_decode_attn_long"] = pts
     except Exception as ex:          # measurement extra only
         extra["roofline_decode_attn_32k"] = {"error": str(ex)}
     return extra

@@ -207,7 +207,9 @@ struct DaPass {
   u32x4_t k[4], v[4], c[4], s[4];
 };
 
-template <int G>
+// DIAG (tools only, SVLM_DA_DIAG): 1 = no rotation arithmetic, 2 = no cos/sin loads, 4 = no MFMA work, 8 = no LDS staging -- timing-only
+// builds that split the per-pass cost; outputs are wrong by construction.
+template <int G, int DIAG = 0>
 __global__ __launch_bounds__(256) void decode_attn_long_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
     const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
@@ -263,9 +265,13 @@ __global__ __launch_bounds__(256) void decode_attn_long_kernel(
       const int slot = slots_s[lr];
       b.k[it] = *reinterpret_cast<const u32x4_t*>(kp + (size_t)slot * DA_D);
       b.v[it] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)slot * DA_D);
-      const bf16_t* csr = rope_cs + (size_t)(start + lr) * DA_D;
-      b.c[it] = *reinterpret_cast<const u32x4_t*>(csr + fc);
-      b.s[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
+      if constexpr (DIAG & 2) {
+        b.c[it] = b.k[it]; b.s[it] = b.v[it];
+      } else {
+        const bf16_t* csr = rope_cs + (size_t)(start + lr) * DA_D;
+        b.c[it] = *reinterpret_cast<const u32x4_t*>(csr + fc);
+        b.s[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
+      }
     }
   };
   auto stage = [&](int p, const DaPass& b) {
@@ -275,13 +281,23 @@ __global__ __launch_bounds__(256) void decode_attn_long_kernel(
       u32x4_t kp4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) kp4[i] = dpp_u<0x128>(b.k[it][i]);
-      float x[8], xp[8], cc[8], sn[8], o[8];
-      unpack8(b.k[it], x); unpack8(kp4, xp); unpack8(b.c[it], cc); unpack8(b.s[it], sn);
-      rope8(x, xp, cc, sn, upper, o);
       const bool ok = p * 64 + lrow < n_rows;
       const u32x4_t z = u32x4_t{0, 0, 0, 0};
-      *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = ok ? pack8(o) : z;
-      *reinterpret_cast<u32x4_t*>(Vs + lrow * DA_VLD + c * 8) = ok ? b.v[it] : z;
+      u32x4_t kr;
+      if constexpr (DIAG & 1) {
+        kr = b.k[it] ^ b.c[it] ^ b.s[it] ^ kp4;
+      } else {
+        float x[8], xp[8], cc[8], sn[8], o[8];
+        unpack8(b.k[it], x); unpack8(kp4, xp); unpack8(b.c[it], cc); unpack8(b.s[it], sn);
+        rope8(x, xp, cc, sn, upper, o);
+        kr = pack8(o);
+      }
+      if constexpr (DIAG & 8) {
+        asm volatile("" ::"v"(kr), "v"(b.v[it]));
+      } else {
+        *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = ok ? kr : z;
+        *reinterpret_cast<u32x4_t*>(Vs + lrow * DA_VLD + c * 8) = ok ? b.v[it] : z;
+      }
     }
   };
 
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(256) void decode_attn_long_kernel(
   auto compute = [&](int p) {
     const int base = p * 64 + wave * 16;                    // this wave's tile of the pass
     if (base >= n_rows) return;                             // wave-uniform
+    if constexpr (DIAG & 4) return;
     f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -351,6 +368,203 @@ __global__ __launch_bounds__(256) void decode_attn_long_kernel(
     lds_barrier();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the trailing redundant loads must not outlive the wave's registers
+  if (fr < G) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_D) + dt * 16 + fq * 4) = oacc[dt];
+    if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
+  }
+  __syncthreads();
+  const size_t part = (size_t)blockIdx.x * Hq;
+  for (int idx = tid; idx < G * DA_D; idx += 256) {
+    const int g = idx / DA_D, d = idx % DA_D;
+    float mn = Mm[g];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) mn = fmaxf(mn, Mm[w * 16 + g]);
+    float l = 0.f, a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float e = __expf(Mm[w * 16 + g] - mn);
+      l += Lm[w * 16 + g] * e;
+      a += Om[(w * 16 + g) * DA_D + d] * e;
+    }
+    const int hq = kvh * G + g;
+    ws_acc[(part + hq) * DA_D + d] = a;
+    if (d == 0) { ws_m[part + hq] = mn; ws_l[part + hq] = l; }
+  }
+}
+
+// Streaming variant for long caches (chunk % 64 == 0): the multi-pass kernel above meets at two workgroup barriers per 64-key pass,
+// which leaves it latency-bound (built with no arithmetic at all it still needs 23 of its 30 us at 32k keys x 4 kv heads:
+// tools/decode_attn_sweep.py with SVLM_DA_DIAG).  Here every WAVE is its own pipeline over 16-key tiles (wave w takes tiles w, w+4,
+// ... of the workgroup's key range) with NO barrier in the loop:
+//   * K rows are loaded straight into the MFMA A-operand layout: lane (key = lane & 15, fq = lane >> 4) takes the four 16-B pieces
+//     d = 32 ks + 8 fq .. + 7 (ks = 0..3) of its key's row -- a key's rotation partner d +- 64 is piece ks +- 2 of the SAME lane, so
+//     RoPE-on-load is lane-local arithmetic on registers, with the cos / sin pieces loaded in the same pattern (whole 256-B rows
+//     through a second LDS slab were measured too: same speed at 32k keys, 4-10 % slower at 131k);
+//   * V rows go through a 4.5 KB LDS slab PRIVATE to the wave (ds_write_b128, then the transposing ds_read_b64_tr_b16 of the
+//     kernel above): LDS operations of one wave execute in order, no barrier is needed;
+//   * the loads of the wave's NEXT tile (K, cos/sin, V: 12 KB per wave) are in flight while the current one is rotated and
+//     multiplied; 12 resident waves per CU keep ~140 KB per CU in flight.
+// Everything after the loop (4-wave merge, fp32 partials for decode_attn_combine_kernel) is the multi-pass kernel's.
+// Measured (MI355X, tools/decode_attn_sweep.py, split + combine): 4 kv heads x 131k keys 71 us = 3.8 TB/s of K/V; 4 x 32k 25.8 us
+// (multi-pass kernel 30.6); 2 x 32k 17.4 us (one-pass kernel 21.0).
+#define DA_STREAM_TPW 8          // tiles per wave: chunk <= 16 * 4 * 8 = 512 keys per workgroup
+struct DaTile {
+  u32x4_t k[4], cs[4], v[4];     // K pieces ks = 0..3; cos pieces 0,1 and sin pieces 0,1; V rows 4 i + (lane >> 4), chunk lane & 15
+};
+
+template <int G>
+__global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
+    const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
+    float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
+    int chunk, float scale, int max_len) {
+  // LDS: [4][16][128] fp32 merge buffer (32 KB), whose first 18 KB double as the four waves' V slabs during the loop; Q block; m / l
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 16 * DA_D * 4 + 16 * DA_KLD * 2 + 512];
+  float* Om = reinterpret_cast<float*>(lds);
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(lds + 4 * 16 * DA_D * 4);
+  float* Mm = reinterpret_cast<float*>(lds + 4 * 16 * DA_D * 4 + 16 * DA_KLD * 2);
+  float* Lm = Mm + 64;
+
+  const int start = blockIdx.x * chunk;
+  const int kvh = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16_t* Vw = reinterpret_cast<bf16_t*>(lds) + wave * 16 * DA_VLD;       // this wave's V slab: 16 rows x 288 B
+  const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D;
+  const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D;
+
+  // slot of key (lane & 15) in each of the wave's tiles (stale / clamped entries are valid slots; masked later)
+  int slot_t[DA_STREAM_TPW];
+#pragma unroll
+  for (int t = 0; t < DA_STREAM_TPW; ++t) slot_t[t] = slot_of[min(start + (t * 4 + wave) * 16 + fr, max_len - 1)];
+  // rotated query block -> Qs (rows >= G are zero), exactly as the kernels above
+  {
+    const int srow = tid >> 4, c = tid & 15;
+    u32x4_t qraw = u32x4_t{0, 0, 0, 0};
+    if (srow < G) qraw = *reinterpret_cast<const u32x4_t*>(q + (size_t)(kvh * G + srow) * DA_D + c * 8);
+    const int Lq = (len_dev ? *len_dev : 0) + len_add;
+    const bf16_t* csq = rope_cs + (size_t)(max(Lq, 1) - 1) * DA_D;
+    const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + (c & 7) * 8);
+    const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + (c & 7) * 8);
+    u32x4_t outq = u32x4_t{0, 0, 0, 0};
+    u32x4_t rp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rp[i] = dpp_u<0x128>(qraw[i]);
+    if (srow < G) {
+      float x[8], xp[8], cc[8], sn[8], o[8];
+      unpack8(qraw, x); unpack8(rp, xp); unpack8(qc, cc); unpack8(qs, sn);
+      rope8(x, xp, cc, sn, c >= 8, o);
+      outq = pack8(o);
+    }
+    *reinterpret_cast<u32x4_t*>(Qs + srow * DA_KLD + c * 8) = outq;
+  }
+  const int L = (len_dev ? *len_dev : 0) + len_add;
+  if (start >= L) return;                                   // workgroup-uniform
+  const int n_rows = min(chunk, L - start);
+  const int n_tiles = (n_rows + 15) >> 4;                   // of the workgroup; wave w owns tiles w, w + 4, ...
+  __syncthreads();                                          // Qs visible
+  bf16x8_t qf[4];                                           // this lane's B fragments of the query block: constant over the loop
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + fr * DA_KLD + ks * 32 + fq * 8);
+
+  auto load_tile = [&](int t, int slot_own, DaTile& b) {
+    // K in operand layout: piece ks of row `slot_own`; cos / sin pieces of the key's logical row
+    const bf16_t* krow = kp + (size_t)slot_own * DA_D + fq * 8;
+    const int lrow = min(start + (t * 4 + wave) * 16 + fr, max_len - 1);
+    const bf16_t* csr = rope_cs + (size_t)lrow * DA_D + fq * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b.k[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(krow + ks * 32));
+    b.cs[0] = *reinterpret_cast<const u32x4_t*>(csr);
+    b.cs[1] = *reinterpret_cast<const u32x4_t*>(csr + 32);
+    b.cs[2] = *reinterpret_cast<const u32x4_t*>(csr + 64);
+    b.cs[3] = *reinterpret_cast<const u32x4_t*>(csr + 96);
+    // V rows for the slab: row 4 i + fq, 16-B chunk fr; that row's slot sits in lane 4 i + fq
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vslot = __shfl(slot_own, 4 * i + fq, 64);
+      b.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vp + (size_t)vslot * DA_D + fr * 8));
+    }
+  };
+
+  float m_w = -1e30f, l_w = 0.f;
+  f32x4_t oacc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int t, const DaTile& b) {
+    const int base = (t * 4 + wave) * 16;                   // first key of the tile, relative to `start`
+    // ---- RoPE on registers: out(d) = bf(bf(x c) + bf(rot s)), rot = -x(d + 64) for d < 64, x(d - 64) above
+    bf16x8_t kf[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float xl[8], xu[8], cc[8], sn[8], ol[8], ou[8];
+      unpack8(b.k[h], xl); unpack8(b.k[h + 2], xu); unpack8(b.cs[h], cc); unpack8(b.cs[2 + h], sn);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ol[i] = rbf(rbf(xl[i] * cc[i]) + rbf(-xu[i] * sn[i]));
+        ou[i] = rbf(rbf(xu[i] * cc[i]) + rbf(xl[i] * sn[i]));
+      }
+      u32x4_t pl = pack8(ol), pu = pack8(ou);
+      kf[h] = *reinterpret_cast<bf16x8_t*>(&pl);
+      kf[h + 2] = *reinterpret_cast<bf16x8_t*>(&pu);
+    }
+    // ---- V to the wave's slab (LDS operations of one wave are executed in order: no barrier)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(Vw + (4 * i + fq) * DA_VLD + fr * 8) = b.v[i];
+    f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
+    float sc[4], mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = base + fq * 4 + r < n_rows;
+      sc[r] = ok ? sacc[r] * scale : -1e30f;
+      mx = fmaxf(mx, sc[r]);
+    }
+    const float m_new = fmaxf(m_w, xor32_max(xor16_max(mx)));
+    const float alpha = __expf(m_w - m_new);
+    float p8[8], rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p8[r] = sc[r] > -1e29f ? __expf(sc[r] - m_new) : 0.f;
+      p8[r + 4] = 0.f;
+      rs += p8[r];
+    }
+    l_w = l_w * alpha + xor32_sum(xor16_sum(rs));
+    m_w = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+    u32x4_t pk = pack8(p8);
+    const bf16x8_t pb = *reinterpret_cast<bf16x8_t*>(&pk);
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16_t* vr = Vw + (fq * 4 + (fr >> 2)) * DA_VLD + dt * 16 + (fr & 3) * 4;
+      const v4s_da_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_da_t*)(vr));
+      const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], lo[0], lo[1], lo[2], lo[3]};   // upper k-slots meet P == 0
+      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
+    }
+  };
+
+  // software pipeline, two named tile buffers; a wave's tile index runs 0 .. nt - 1 (workgroup tile 4 t + wave)
+  const int nt = n_tiles > wave ? (n_tiles - wave + 3) >> 2 : 0;   // tiles of this wave
+  DaTile A, B;
+  if (nt > 0) load_tile(0, slot_t[0], A);
+#pragma unroll
+  for (int t = 0; t < DA_STREAM_TPW; t += 2) {
+    if (t >= nt) break;                                     // wave-uniform
+    if (t + 1 < DA_STREAM_TPW) load_tile(min(t + 1, nt - 1), slot_t[t + 1 < DA_STREAM_TPW ? t + 1 : t], B);      // redundant reload at the end: harmless
+    __builtin_amdgcn_sched_barrier(0);
+    compute(t, A);
+    if (t + 1 >= nt) break;
+    if (t + 2 < DA_STREAM_TPW) load_tile(min(t + 2, nt - 1), slot_t[t + 2 < DA_STREAM_TPW ? t + 2 : t], A);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(t + 1, B);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // trailing redundant loads must not outlive the registers
+  __syncthreads();                                          // every wave is done with its V slab: the region becomes the merge buffer
   if (fr < G) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_D) + dt * 16 + fq * 4) = oacc[dt];
@@ -481,8 +695,26 @@ template <int G>
 static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* kp, const bf16_t* vp, const int* slot_of,
                          const bf16_t* cs, const int* len_dev, int len_add, float* ws_m, float* ws_l, float* ws_acc, int Hq, int Hkv,
                          int n_slots, int chunk, float scale, int max_len) {
-  if (chunk > 16 * DA_MAX_STEPS)
+  static const int diag = getenv("SVLM_DA_DIAG") ? atoi(getenv("SVLM_DA_DIAG")) : 0;
+  static const bool stream_k = getenv("SVLM_DA_STREAM") == nullptr || atoi(getenv("SVLM_DA_STREAM")) != 0;
+  if (chunk > 16 * DA_MAX_STEPS && stream_k && diag == 0 && chunk <= 64 * DA_STREAM_TPW) {
+    decode_attn_stream_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+    return;
+  }
+  if (chunk > 16 * DA_MAX_STEPS) {
+    if constexpr (G == 6 || G == 7) {
+      switch (diag) {
+        case 1: decode_attn_long_kernel<G, 1><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
+        case 2: decode_attn_long_kernel<G, 2><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
+        case 3: decode_attn_long_kernel<G, 3><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
+        case 4: decode_attn_long_kernel<G, 4><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
+        case 7: decode_attn_long_kernel<G, 7><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
+        case 15: decode_attn_long_kernel<G, 15><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
+        default: break;
+      }
+    }
     decode_attn_long_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+  }
   else
     decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
 }

@@ -699,6 +699,22 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       else
         gemm_glds_kernel<10, 2><<<grid, 256, DLDS10, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                   (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+    } else if (small && splits == 1 && getenv("SVLM_GEMM_NS3") == nullptr) {
+      // un-split 64-row tiles on a 2-stage ring: 48 KB of LDS, THREE workgroups per CU -- one tile in flight each, the others' MFMAs
+      // cover its wait.  Measured against the 3-stage ring (72 KB, two per CU; tools/gemm_shapes.py shapes, MI355X): ViT fc1
+      // 31.5 -> 26.6 us, prefill gate/up 36.5 -> 31.2 us, ViT qkv 21.4 -> 20.9 us; split-K shapes are unchanged and keep 3 stages.
+      constexpr int DLDS2S = 2 * (64 + GEMM_BN) * 128;
+      static bool ns2_done = false;
+      if (!ns2_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS2S);
+        if (e1 != hipSuccess) {
+          svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", DLDS2S, hipGetErrorString(e1));
+          return SVLM_ELAUNCH;
+        }
+        ns2_done = true;
+      }
+      gemm_glds_kernel<2, 2><<<grid, 256, DLDS2S, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                               (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
     } else if (small) {
       gemm_glds_kernel<2, NS2><<<grid, 256, DLDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);

@@ -318,13 +318,15 @@ class SvlmEngine:
     def pick_decode_chunk(max_len: int, n_kv_heads: int) -> int:
         """Keys per decode-attention workgroup (measured on MI355X, tools/decode_attn_sweep.py): 48 at the bounded windows
         of the streaming configs (2B @ 2048: 8.5 us, 7B @ 4096: 12.3 us; fewer, fatter splits starve the chip, more of them
-        bloat the combine), 64 for long caches, and the multi-pass kernel (256 keys) once there are >= 4 kv heads of a
-        32k-class cache, where one-pass splits would mean thousands of partials."""
+        bloat the combine).  Long caches run the barrier-free streaming kernel (chunk > 64): 128 keys while the cache is small
+        enough that workgroup count matters (2 kv heads x 32k: 17.9 us; x 8k: 11.3), 192 from ~100k head-keys (4 x 32k: 26.0 us;
+        256 is 10 % slower there: 64 KB strides between workgroups), 512 for the very long ones (4 x 131k: 73 us = 3.7 TB/s)."""
         if max_len <= 1024:
             return max(16, 16 * int(math.ceil(max_len / 64 / 16)))
         if max_len <= 6144:
             return 48
-        return 256 if max_len * n_kv_heads >= 100_000 else 64
+        hk = max_len * n_kv_heads
+        return 128 if hk < 100_000 else (192 if hk < 400_000 else 512)
 
     # ------------------------------------------------------------------ cache
     def new_cache(self, page_tokens: Optional[int] = None, slack: Optional[float] = None) -> KVPool:
