@@ -303,8 +303,11 @@ class SvlmEngine:
         # ViT blocks of a look-ahead pass held back for the gap between chunks (~0.19 ms each at 448x448 on the 2B tower)
         self.vit_tail = int(os.environ.get("SVLM_VIT_TAIL", 5))
         self.section_events = None         # bench: [] -> generate() appends (name, start event, end event) of its ViT / prefill phases
-        self._graph = None
-        self._graph_key = None
+        # captured decode-step graphs, keyed by (pool serial, sampling configuration, attention geometry); each entry keeps a strong
+        # reference to its pool (the graph holds raw pointers into it); a few streams can alternate on one engine without re-capturing
+        self._graphs = {}
+        self._graph = None                 # the one replayed last (tools read it)
+        self.max_graphs = 4
         self._penalty = 1.0
         self._suppress = None
         # token choice: None = greedy, else (temperature, top_k, top_p); HF GenerationConfig's own defaults for a model that does not
@@ -539,14 +542,18 @@ class SvlmEngine:
             self._decode_step_launch(c)
             self._sample_launch(1, fused=True)
             return
-        key = (id(c), self._penalty, self._suppress is not None, self._sampling, self.decode_chunk, self._attn_len)
-        if self._graph is None or self._graph_key != key:
+        key = (c.serial, self._penalty, self._suppress is not None, self._sampling, self.decode_chunk, self._attn_len)
+        hit = self._graphs.get(key)
+        if hit is None:
             # capture once per (cache, sampling config); state is restored because capture does not execute
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._decode_step_launch(c)
                 self._sample_launch(1, fused=True)
-            self._graph, self._graph_key = g, key
+            if len(self._graphs) >= self.max_graphs:
+                self._graphs.pop(next(iter(self._graphs)))          # oldest capture (and its pool reference) goes
+            hit = self._graphs[key] = (g, c)
+        self._graph = hit[0]
         self._graph.replay()
 
     def _mark(self, name=None, start=None):
@@ -698,12 +705,22 @@ class SvlmEngine:
             self._force(0, force_tokens, own, seen_host)
         if next_vision is not None:
             self.vision_prefetch(*next_vision)
+        eos_poll = 0 if (suppress_eos or self.device.type != "cuda") else 4
         for step in range(1, max_new_tokens):
             self._decode_step(cache)
             if keep_logits:
                 logits_out.append(self.logits.detach().cpu().clone())
             if own is not None:
                 self._force(step, force_tokens, own, seen_host)
+            # a real caption ends well before max_new_tokens: every 4th step the tokens so far are looked at (one small D2H + sync)
+            # and the remaining steps are not launched once an end-of-turn token is among them; with EOS suppressed (benchmarks:
+            # fixed token counts) nothing is polled and the chunk keeps its single host sync
+            if eos_poll and step % eos_poll == 0 and step + 1 < max_new_tokens:
+                self._tok_host[:step + 1].copy_(self.tok_buf[:step + 1], non_blocking=True)
+                self._tok_ev.record()
+                self._tok_ev.synchronize()
+                if any(int(t) in cfg.eos_token_ids for t in self._tok_host[:step + 1].tolist()):
+                    break
         # the one host sync of the chunk waits for the TOKENS only: the held-back ViT tail of the look-ahead pass is enqueued
         # behind the copy and keeps the GPU busy while the host turns the chunk around
         if self.device.type == "cuda":

@@ -41,6 +41,8 @@ class _LayerPlanes:
 
 
 class KVPool:
+    _next_serial = 0          # pools are numbered: a captured decode graph is keyed by the serial of the pool whose buffers it holds
+
     def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_len: int, device, ops, page_tokens: int = 16,
                  slack: float = 1.0):
         """max_len: the largest logical length the stream ever reaches (sink + window + one chunk)."""
@@ -63,6 +65,8 @@ class KVPool:
         self.open_fill = page_tokens
         self._dirty_from = 0
         self.stats = dict(moved_rows=0, defrags=0, evicted_rows=0)
+        KVPool._next_serial += 1
+        self.serial = KVPool._next_serial
         self.key_cache, self.value_cache = _LayerPlanes(self, 0), _LayerPlanes(self, 1)
         # pos_mode="append": the M-RoPE position of every cached row, edited in lockstep with slot_of (float64 holds the
         # int positions of Qwen2-VL and the float32 ones of Qwen2.5-VL exactly)

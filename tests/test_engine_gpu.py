@@ -179,6 +179,43 @@ def test_graph_replay_equals_eager_launches():
             assert torch.equal(x, y)
 
 
+def test_two_streams_alternating_on_one_engine_keep_their_graphs():
+    """Two KV pools taking turns on one engine (two streams sharing a model replica): each pool's decode graph is captured once and
+    found again by the pool's serial -- the engine holds the pool while it holds the graph -- and both streams produce what they
+    produce alone."""
+    import streaming_vlm_amd as S
+    cfg, sd, model = _tiny_model()
+    eng = model._svlm_engine
+    alone = []
+    for stream in (0, 1):
+        c2, s2, m2 = _tiny_model()
+        log = []
+        S.streaming_inference(model=m2, processor=S.SyntheticProcessor(), video_path=f"synthetic://56x56@1fps?stream={stream}", model_base="Qwen2",
+                              duration=4, kv_policy="sink_window", sink=4, window=64, do_sample=False, max_new_tokens=8, suppress_eos=True,
+                              quiet=True, ids_log=log, vision_lookahead=False)
+        alone.append([e["new"] for e in log])
+    proc = S.SyntheticProcessor()
+    vids = [S.SyntheticVideo(56, 1.0, s) for s in (0, 1)]
+    srcs = [H.chunk_source(proc, v, "") for v in vids]
+    caches, hist, got, grids = [None, None], [None, None], [[], []], [[], []]
+    for i in range(4):
+        for s in (0, 1):
+            ids, pix, grid = srcs[s](i)
+            if hist[s] is not None:
+                ids = hist[s] + (ids[1:] if hist[s][-1] == 198 else ids)
+            grids[s] = grids[s] + [list(g) for g in grid]
+            out = eng.generate(ids, caches[s], grids[s], pix.cuda(), grid, max_new_tokens=8, repetition_penalty=1.05, suppress_eos=True)
+            caches[s] = out.past_key_values
+            seq = out.sequences + ([151645] if out.sequences[-1] != 151645 else [])
+            got[s].append(seq[len(ids):])
+            hist[s] = seq
+    assert len(eng._graphs) == 2, list(eng._graphs)                     # one capture per pool, none dropped or redone
+    assert {k[0] for k in eng._graphs} == {caches[0].serial, caches[1].serial}
+    # (the hand-driven pair never evicts: compare the chunks that come before the driver's first eviction)
+    for s in (0, 1):
+        assert got[s][:2] == alone[s][:2], (s, got[s][:2], alone[s][:2])
+
+
 def test_golden_streams_eviction_trace_and_tokens():
     """Committed oracle streams (tests/golden/oracle_streams.json, minted in the build container by oracle/make_golden.py
     with the decisive weights) replayed on the HIP engine with NO oracle in the loop: eviction indices, KV lengths and EVERY
