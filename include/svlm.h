@@ -128,6 +128,18 @@ int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len, int H, int
 int svlm_mrope_table(const int* pos3, const float* posf3, int pos_stride, const float* inv_freq, void* rope_cs, int start,
                      int count, int head_dim, int sec_t, int sec_h, int sec_w, void* stream);
 
+/* M-RoPE position ids of a whole id sequence, computed on the device: ids (L) and grids (n_grids, 3) [t, h, w in
+ * patches] int32 in device memory -> pos3 (3, stride) int32, or posf3 fp32 with the Qwen2.5 temporal scaling
+ * ((t * second_per_grid_t) * tokens_per_second, then + text_len + start, in the reference's order); rows [L, L + n_extra) continue
+ * the trailing text run (the tokens about to be generated).  ws >= svlm_rope_index_ws_bytes(L, n_grids); its first int receives
+ * 0 or the reference's failure (2: more spans than grid rows, 3: span without video tokens, 4: span past the end).
+ * replaces: get_rope_index, inference/qwen2/pos_emb.py:69-133 (Qwen2.5: inference/qwen2_5/pos_emb.py:107-160), recomputed there
+ * in Python on every forward (qwen2/model_forward.py:119-126). */
+long long svlm_rope_index_ws_bytes(int max_len, int max_spans);
+int svlm_rope_index(const int* ids, int L, const int* grids, int n_grids, int merge, int video_token_id, int vision_start_token_id,
+                    int* pos3, float* posf3, int stride, float second_per_grid_t, float tokens_per_second, int n_extra, void* ws,
+                    long long ws_bytes, void* stream);
+
 /* Append T un-rotated K/V rows of one layer at logical rows base..base+T-1 (base = *len_dev or start).
  * replaces: StreamingCache.update = torch.cat (generate/streaming_cache.py:72-73). */
 int svlm_kv_append(const void* k_new, int k_stride, const void* v_new, int v_stride, void* k_planes, void* v_planes,

@@ -282,12 +282,18 @@ class SvlmEngine:
         self.tok_buf = torch.zeros(self.max_new + 1, dtype=torch.int32, device=dev)
         if dev.type == "cuda":
             self._tok_host = torch.zeros(self.max_new + 1, dtype=torch.int32).pin_memory()
+            self._pos_status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._tok_ev = torch.cuda.Event()
         self.state = torch.zeros(2, dtype=torch.int32, device=dev)          # [kv_len, cur]
         self.seen = torch.zeros(V, dtype=torch.uint8, device=dev)
         self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
         self.eos_dev = torch.tensor(list(cfg.eos_token_ids), dtype=torch.int32, device=dev)
         self.ids_dev = torch.zeros(self.max_len, dtype=torch.int32, device=dev)
+        # device-side position bookkeeping: M-RoPE ids are derived from ids_dev + the span grid table by svlm_rope_index
+        self.max_spans = max(64, self.max_len // 64)
+        self.grids_dev = torch.zeros((self.max_spans, 3), dtype=torch.int32, device=dev)
+        self.pos_ws = ops.rope_index_ws(self.max_len, self.max_spans, dev) if hasattr(ops, "rope_index") else None
+        self.device_positions = self.pos_ws is not None and os.environ.get("SVLM_HOST_POSITIONS", "0") != "1"
         # decode-step static activations
         self.d_x = torch.zeros(H, dtype=BF16, device=dev)
         self.d_xn = torch.zeros(H, dtype=BF16, device=dev)
@@ -613,8 +619,19 @@ class SvlmEngine:
             return rope_index_qwen2(seq, grids, cfg.vision.spatial_merge_size, cfg.video_token_id, cfg.vision_start_token_id)
 
         pos_full = np.empty((3, n_rows), dtype=np.float32 if is_f else np.int32)
-        if pos_mode == "shrink":
-            # positions re-derived from the pruned ids on every chunk (qwen2/model_forward.py:119-126)
+        on_device = pos_mode == "shrink" and self.device_positions and len(video_grid_thw) <= self.max_spans
+        self.ids_dev[:L_ids].copy_(torch.from_numpy(ids.astype(np.int32)), non_blocking=True)
+        if on_device:
+            # shrink mode: positions re-derived from the pruned ids on every chunk (qwen2/model_forward.py:119-126) -- on the device,
+            # from the ids and the span grid table; nothing of size L is computed or copied by the host
+            n_g = 0 if all_text else len(video_grid_thw)
+            if n_g:
+                self.grids_dev[:n_g].copy_(torch.tensor(video_grid_thw, dtype=torch.int32).reshape(n_g, 3), non_blocking=True)
+            pos_dev = self.posf_dev if is_f else self.pos3_dev
+            o.rope_index(self.ids_dev, L_ids, self.grids_dev, n_g, cfg.vision.spatial_merge_size, -1 if all_text else cfg.video_token_id,
+                         -1 if all_text else cfg.vision_start_token_id, pos_dev, self.pos_ws, n_extra=max_new_tokens, second_per_grid_t=spg,
+                         tokens_per_second=cfg.vision.tokens_per_second)
+        elif pos_mode == "shrink":
             pos, nxt = index(ids, video_grid_thw)
             pos_full[:, :L_ids] = pos
         elif pos_mode == "append":
@@ -633,9 +650,10 @@ class SvlmEngine:
             nxt = float(pos[0, -1]) + 1
         else:
             raise ValueError(f"pos_mode must be 'shrink' or 'append', not {pos_mode!r}")
-        pos_full[:, L_ids:] = (np.float32(nxt) if is_f else int(nxt)) + np.arange(max_new_tokens, dtype=pos_full.dtype)
-        pos_dev = self.posf_dev if is_f else self.pos3_dev
-        pos_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
+        if not on_device:
+            pos_full[:, L_ids:] = (np.float32(nxt) if is_f else int(nxt)) + np.arange(max_new_tokens, dtype=pos_full.dtype)
+            pos_dev = self.posf_dev if is_f else self.pos3_dev
+            pos_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
         o.mrope_table(pos_dev, self.inv_freq, self.rope_cs, 0, n_rows, tc.mrope_section)
         cache.reserve(T + max_new_tokens)
         cache.sync_device()
@@ -660,7 +678,6 @@ class SvlmEngine:
         self._penalty = float(repetition_penalty)
         self._suppress = self.eos_dev if suppress_eos else None
         if self._penalty != 1.0:
-            self.ids_dev[:L_ids].copy_(torch.from_numpy(ids.astype(np.int32)))
             self.seen.zero_()
             o.mark_seen(self.ids_dev, L_ids, self.seen)
         self.state.copy_(torch.tensor([L_ids, -1], dtype=torch.int32))
@@ -725,6 +742,8 @@ class SvlmEngine:
         # behind the copy and keeps the GPU busy while the host turns the chunk around
         if self.device.type == "cuda":
             self._tok_host[:max_new_tokens].copy_(self.tok_buf[:max_new_tokens], non_blocking=True)
+            if on_device:
+                self._pos_status_host.copy_(self.pos_ws[:1], non_blocking=True)
             self._tok_ev.record()
             self.vision_prefetch_finish()
             self._tok_ev.synchronize()
@@ -738,8 +757,15 @@ class SvlmEngine:
                 break
         cache.commit(L_ids + n_new - 1)
         cache.release_reserved()
-        cache.pos_rows[:, L_before:cache.length] = pos_full[:, L_before:cache.length]
-        self.last_position = float(pos_full[0, cache.length - 1])           # streaming_args.last_cache_position
+        if on_device:
+            if self.device.type == "cuda":
+                st = int(self._pos_status_host[0])
+                if st:           # the reference raises here too (a span without its tokens / grid row: qwen2/pos_emb.py:88,132)
+                    raise ValueError(f"rope index: malformed vision spans in the id sequence (device status {st})")
+            self.last_position = -1.0            # shrink mode never reads streaming_args.last_cache_position
+        else:
+            cache.pos_rows[:, L_before:cache.length] = pos_full[:, L_before:cache.length]
+            self.last_position = float(pos_full[0, cache.length - 1])           # streaming_args.last_cache_position
         seq = ids.tolist() + [int(t) for t in toks[:n_new]]
         return GenerateOutput(seq, cache, logits_out, n_new, own)
 

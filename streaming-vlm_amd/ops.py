@@ -332,6 +332,22 @@ class HipOps:
                                         _ptr(rope_cs), start, count, D, sections[0], sections[1], sections[2], _stream()),
               "svlm_mrope_table")
 
+    def rope_index_ws(self, max_len, max_spans, device):
+        return torch.zeros((self.lib.svlm_rope_index_ws_bytes(int(max_len), int(max_spans)) + 3) // 4, dtype=torch.int32, device=device)
+
+    def rope_index(self, ids, L, grids, n_grids, merge, video_token_id, vision_start_token_id, pos3, ws, n_extra=0, second_per_grid_t=1.0,
+                   tokens_per_second=2.0):
+        """pos3 (3, stride) int32 or fp32 <- M-RoPE ids of ids[:L] (+ n_extra rows continuing the text run); ws[0] = status."""
+        _req(ids, torch.int32, "rope_index.ids", 1); _req(grids, torch.int32, "rope_index.grids", 2); _req(ws, torch.int32, "rope_index.ws", 1)
+        assert ids.numel() >= L and grids.shape[0] >= n_grids and grids.shape[1] == 3 and grids.is_contiguous()
+        assert pos3.is_cuda and pos3.dim() == 2 and pos3.shape[0] == 3 and pos3.is_contiguous() and L + n_extra <= pos3.shape[1]
+        is_f = pos3.dtype == torch.float32
+        assert is_f or pos3.dtype == torch.int32
+        assert ws.numel() * 4 >= self.lib.svlm_rope_index_ws_bytes(max(int(L), 1), int(n_grids))
+        check(self.lib.svlm_rope_index(_ptr(ids), int(L), _ptr(grids), int(n_grids), int(merge), int(video_token_id), int(vision_start_token_id),
+                                       0 if is_f else _ptr(pos3), _ptr(pos3) if is_f else 0, pos3.shape[1], float(second_per_grid_t),
+                                       float(tokens_per_second), int(n_extra), _ptr(ws), ws.numel() * 4, _stream()), "svlm_rope_index")
+
     @staticmethod
     def _planes(pool, layer):
         # pool (layers, 2, Hkv, n_slots, D)

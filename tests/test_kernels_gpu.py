@@ -703,3 +703,54 @@ def test_vit_tower_fp8_vs_oracle_fp8_and_bf16():
     assert e_hip <= e_fmt + 1e-3
     assert e_hip16 <= 1.25 * e_fmt + 1e-3
     assert e_fmt <= 5e-2
+
+
+# ----------------------------------------------------------------------------- device-side position bookkeeping
+def test_rope_index_on_device_matches_reference_vectors(ops, golden_dir):
+    """svlm_rope_index against the vectors minted from the REFERENCE's own get_rope_index (tests/golden/ref_rope_index.json, incl. a
+    448x448 chunk), against the oracle on long multi-span sequences, and in its Qwen2.5 float form against the oracle's restatement
+    of qwen2_5/pos_emb.py -- exact in every case (fp32 operation order included)."""
+    import json, os
+    from oracle import rope_index as R
+    with open(os.path.join(golden_dir, "ref_rope_index.json")) as f:
+        data = json.load(f)
+    cases = [(name, e["ids"], e["grid"], np.asarray(e["pos"])) for name, e in data.items()]
+    # a long stream: 40 chunks of (text, 256-token span), and a many-frame span (t = 5) with ragged h / w
+    VS, VP, VE = 151652, 151656, 151653
+    ids, grids = [1, 2, 3], []
+    for c in range(40):
+        ids += [10 + c, 11, VS] + [VP] * 256 + [VE, 12, 13, 14]
+        grids.append([1, 32, 32])
+    cases.append(("long_40", ids, grids, R.get_rope_index(ids, grids)))
+    ids2 = [5, VS] + [VP] * (5 * 4 * 3) + [VE, 6, 7, VS] + [VP] * 6 + [VE]
+    g2 = [[5, 8, 6], [1, 4, 6]]
+    cases.append(("t5_ragged", ids2, g2, R.get_rope_index(ids2, g2)))
+    cases.append(("text_only", [1, 2, 3, 4, 5], [], R.get_rope_index([1, 2, 3, 4, 5], [])))
+    for name, ids, grid, want in cases:
+        L, n_extra = len(ids), 7
+        d_ids = torch.tensor(ids, dtype=torch.int32, device="cuda")
+        d_g = torch.tensor(grid if grid else [[0, 0, 0]], dtype=torch.int32, device="cuda").reshape(-1, 3)
+        ws = ops.rope_index_ws(L, len(grid), "cuda")
+        pos = torch.full((3, L + n_extra + 5), -7, dtype=torch.int32, device="cuda")
+        ops.rope_index(d_ids, L, d_g, len(grid), 2, VP, VS, pos, ws, n_extra=n_extra)
+        got = pos.cpu().numpy()
+        assert int(ws[0]) == 0, name
+        assert np.array_equal(got[:, :L], want), name
+        nxt = int(want.max()) + 1 if L else 0
+        assert np.array_equal(got[:, L:L + n_extra], np.tile(nxt + np.arange(n_extra), (3, 1))), name       # the tokens to come
+        assert (got[:, L + n_extra:] == -7).all(), name
+        # float form (Qwen2.5): second_per_grid_t 0.5 and 1.0, tokens_per_second 2
+        for spg in (0.5, 1.0, 0.4):
+            wf = R.get_rope_index_2_5(ids, grid, 2, VP, VS, spg, 2.0)
+            posf = torch.zeros((3, L + n_extra), dtype=torch.float32, device="cuda")
+            ops.rope_index(d_ids, L, d_g, len(grid), 2, VP, VS, posf, ws, n_extra=n_extra, second_per_grid_t=spg, tokens_per_second=2.0)
+            gf = posf.cpu().numpy()
+            assert np.array_equal(gf[:, :L], wf), (name, spg)
+    # the reference's failure cases surface as a status word
+    bad = torch.tensor([VS, VP, VP], dtype=torch.int32, device="cuda")
+    ws = ops.rope_index_ws(3, 1, "cuda")
+    pos = torch.zeros((3, 8), dtype=torch.int32, device="cuda")
+    ops.rope_index(bad, 3, torch.tensor([[1, 4, 4]], dtype=torch.int32, device="cuda"), 1, 2, VP, VS, pos, ws)
+    assert int(ws[0]) == 4                                    # truncated vision span
+    ops.rope_index(bad, 3, torch.tensor([[1, 4, 4]], dtype=torch.int32, device="cuda"), 0, 2, VP, VS, pos, ws)
+    assert int(ws[0]) == 2                                    # a span without a grid row
