@@ -600,10 +600,14 @@ class SvlmEngine:
             raise MemoryError(f"sequence {L_ids}+{max_new_tokens} exceeds engine max_len {self.max_len}")
         dev = self.device
         if self._fixed_chunk is None:
-            # decode-attention geometry of THIS call: split size from the current length, grid bounded by it (rounded up to 1k rows
-            # so that a steady stream keeps one captured graph)
-            self.decode_chunk = self.pick_decode_chunk(L_ids + max_new_tokens, tc.num_kv_heads)
-            self._attn_len = min(self.max_len, -(-(L_ids + max_new_tokens) // 1024) * 1024)
+            # decode-attention geometry of THIS call: split size from the current length, grid bounded by it.  The bound moves in
+            # steps of 1k rows up to 8k and of 8k rows beyond (a cache that only grows -- full-attention mode -- would otherwise
+            # re-capture its 171-kernel decode graph every few chunks: 5-8 ms each time, seen as 7 ms/token spikes in
+            # tools/efficiency_modes.py mode a), and the split size is picked for the bound, so both change together.
+            need = L_ids + max_new_tokens
+            step = 1024 if need <= 8192 else 8192
+            self._attn_len = min(self.max_len, -(-need // step) * step)
+            self.decode_chunk = self.pick_decode_chunk(self._attn_len, tc.num_kv_heads)
         # ---- shrink-mode positions for the whole (pruned) sequence + the tokens to be generated
         n_rows = L_ids + max_new_tokens
         is_f = cfg.family == "qwen2_5" and not all_text

@@ -40,9 +40,22 @@ elif which == "decode_attn":
     ch = int(os.environ.get("MB_CHUNK", 48))          # keys per workgroup: the engine's choice for bounded windows
     ws = o.decode_attn_ws(Hq, 2560, ch, dev)
     fn = lambda: o.decode_attn(q, pool, 0, slot, rope, out, ws, Hq, 2560, ch, 128 ** -0.5, length=L)
+elif which == "decode_attn_long":
+    # long-cache streaming kernel: 8 cold pools at MB_L keys (default 32768) with MB_HEADS = "Hq,Hkv" (default the 7B's 28,4)
+    Hq, Hkv = (int(v) for v in os.environ.get("MB_HEADS", "28,4").split(","))
+    L = int(os.environ.get("MB_L", 32768))
+    cap = L + 64
+    from streaming_vlm_amd.engine import SvlmEngine
+    ch = SvlmEngine.pick_decode_chunk(cap, Hkv)
+    pools = [r(1, 2, Hkv, cap, 128) for _ in range(8)]
+    slot = torch.arange(cap, dtype=torch.int32, device=dev)
+    rope = r(cap, 128)
+    q, out = r(Hq * 128), torch.empty(Hq * 128, dtype=bf, device=dev)
+    ws = o.decode_attn_ws(Hq, cap, ch, dev)
+    fn = lambda: [o.decode_attn(q, p, 0, slot, rope, out, ws, Hq, cap, ch, 128 ** -0.5, length=L) for p in pools]
 elif which == "dec_gate_up":
-    # 28 DIFFERENT weight matrices (1.5 GB > Infinity Cache), like the 28 layers of a decode step
-    H, I = 1536, 8960
+    # 28 DIFFERENT weight matrices (1.5 GB > Infinity Cache), like the 28 layers of a decode step; MB_MODEL=7b: the 7B's shapes
+    H, I = (3584, 18944) if os.environ.get("MB_MODEL") == "7b" else (1536, 8960)
     Ws = [r(2 * I, H) for _ in range(28)]
     x, lnw, h = r(H), r(H), torch.empty(I, dtype=bf, device=dev)
     fn = lambda: [o.dec_gate_up(x, lnw, 1e-6, W, h) for W in Ws]
