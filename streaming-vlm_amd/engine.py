@@ -401,14 +401,18 @@ class SvlmEngine:
             row, i = row + n, j
         return torch.cat(outs, 0)
 
-    def vision_prefetch(self, pixel_values, grid_thw):
+    def vision_prefetch(self, pixel_values, grid_thw, after=None):
         """Enqueue the ViT + merger of the NEXT chunk's frames.  Frames do not depend on generated text, so most of the
         pass runs on a side stream underneath this chunk's decode steps (HBM/latency-bound GEMVs that leave the MFMA
         pipes idle).  The side stream starts after everything already enqueued on the current stream (this chunk's
         prefill: the two never run GEMMs at the same time, so the split-K scratch is not shared).  The last `vit_tail`
         blocks and the merger are held back for `vision_prefetch_finish`, which puts them on the MAIN stream behind the
         last decode step: they run during the host's turnaround between chunks, when the GPU would otherwise idle.
-        `generate` of the next chunk picks the features up when it is handed the SAME pixel tensor."""
+        `generate` of the next chunk picks the features up when it is handed the SAME pixel tensor.
+        `after`: an event on the main stream the pass may start behind (default: everything enqueued there so far).  `generate`
+        enqueues its decode replays FIRST and these ~290 eager launches behind them, with `after` = the point in front of the decode
+        steps: the launches cost the host ~3 ms, and issued ahead of the replays they delayed the first decode step by as much
+        (tools/vit_overlap.py: 22.0 -> 21.1 ms for 19 steps + one pass)."""
         if self.device.type != "cuda":
             return
         self._vision_drain()
@@ -417,7 +421,10 @@ class SvlmEngine:
             # decode workgroups are not dispatch-starved, they share HBM and CUs with the ViT tiles)
             self._vis_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
-        self._vis_stream.wait_stream(main)
+        if after is not None:
+            self._vis_stream.wait_event(after)
+        else:
+            self._vis_stream.wait_stream(main)
         depth = self.cfg.vision.depth
         tail = min(max(self.vit_tail, 0), depth)
         with torch.cuda.stream(self._vis_stream):
@@ -724,8 +731,10 @@ class SvlmEngine:
             max_new_tokens = len(force_tokens)
             own, seen_host = [], set(int(t) for t in ids)
             self._force(0, force_tokens, own, seen_host)
-        if next_vision is not None:
-            self.vision_prefetch(*next_vision)
+        ev_pre = None
+        if next_vision is not None and self.device.type == "cuda":
+            ev_pre = torch.cuda.Event()
+            ev_pre.record()                 # the look-ahead ViT may start here: behind the prefill, beside the decode steps
         eos_poll = 0 if (suppress_eos or self.device.type != "cuda") else 4
         for step in range(1, max_new_tokens):
             self._decode_step(cache)
@@ -749,6 +758,8 @@ class SvlmEngine:
             if on_device:
                 self._pos_status_host.copy_(self.pos_ws[:1], non_blocking=True)
             self._tok_ev.record()
+            if next_vision is not None:      # decode replays are in the queue: now the host can spend its 3 ms on the ViT launches
+                self.vision_prefetch(*next_vision, after=ev_pre)
             self.vision_prefetch_finish()
             self._tok_ev.synchronize()
             toks = self._tok_host[:max_new_tokens].numpy().copy()

@@ -10,7 +10,8 @@ from streaming_vlm_amd.weights import random_state_dict
 from streaming_vlm_amd.synthetic import ResidentVideo, ResidentProcessor
 
 cfg = C.qwen2_vl_2b()
-model = S.StreamingQwen2VL(cfg, random_state_dict(cfg, 0, "cuda"), "cuda", max_len=2700, max_new_tokens=20)
+FP8 = "--fp8" in sys.argv          # the fp8 tower: half the operand bytes through L2 -- does the look-ahead interfere less?
+model = S.StreamingQwen2VL(cfg, random_state_dict(cfg, 0, "cuda"), "cuda", max_len=2700, max_new_tokens=20, vit_fp8=FP8)
 eng = model._svlm_engine
 video = ResidentVideo(12, 448, 1.0, 0, "cuda")
 S.streaming_inference(model=model, processor=ResidentProcessor(), video=video, model_base="Qwen2", duration=10, previous_text="",
@@ -38,7 +39,39 @@ def both():
         eng.vision_forward(pix, grid)
     decode()
     torch.cuda.current_stream().wait_stream(side)
-print(f"decode x19 alone {t(decode):.3f} ms | vit alone {t(vit):.3f} ms | decode with vit on a side stream {t(both):.3f} ms")
+def both_decode_first():
+    # the decode replays are enqueued FIRST (0.3 ms of host time), the ~290 eager ViT launches (~3 ms of host time) behind them:
+    # the side stream only waits for what was on the main stream BEFORE the decode steps
+    ev = torch.cuda.Event()
+    ev.record()
+    decode()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        eng.vision_forward(pix, grid)
+    torch.cuda.current_stream().wait_stream(side)
+print(f"decode enqueued first, then the vit launches: {t(both_decode_first):.3f} ms", flush=True)
+# the whole pass as ONE captured graph on the side stream: no host launch time at all
+gv = torch.cuda.CUDAGraph()
+eng.vision_forward(pix, grid); torch.cuda.synchronize()
+with torch.cuda.graph(gv, stream=side):
+    vis_static = eng.vision_forward(pix, grid)
+torch.cuda.synchronize()
+def both_graph():
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        gv.replay()
+    decode()
+    torch.cuda.current_stream().wait_stream(side)
+def vit_graph():
+    with torch.cuda.stream(side):
+        gv.replay()
+    torch.cuda.current_stream().wait_stream(side)
+print(f"vit as one graph: alone {t(vit_graph):.3f} ms | beside the decode replays {t(both_graph):.3f} ms", flush=True)
+print(f"[{'fp8' if FP8 else 'bf16'} vit] decode x19 alone {t(decode):.3f} ms | vit alone {t(vit):.3f} ms | decode with vit on a side stream {t(both):.3f} ms", flush=True)
+if FP8:
+    sys.exit(0)
 
 # ---- the same question for the prefill: ViT of the next chunk beside THIS chunk's prefill (both GEMM streams, one tile per CU each)
 import copy
