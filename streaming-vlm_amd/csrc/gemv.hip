@@ -6,6 +6,7 @@
 // Replaces the decode-step Linear calls of qwen2/language_forward.py:80-82,161, Qwen2MLP (:201)
 // and the last-row lm_head of qwen2/model_forward.py:243.
 #include "common.h"
+#include <stdlib.h>
 
 template <int ROWS>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W, int ldw,
@@ -164,10 +165,11 @@ extern "C" int svlm_gemv_bf16(const void* x, const void* W, int ldw, const void*
     return svlm_check_launch("svlm_gemv_bf16(ksplit)");
   }
   // rows per wave: keep >= ~2 waves of work per SIMD on 256 CUs, amortise x over up to 4 rows
-  if (N >= 16384) {
+  static const int force_rows = getenv("SVLM_GEMV_ROWS") ? atoi(getenv("SVLM_GEMV_ROWS")) : 0;     // tuning aid
+  if (force_rows == 4 || (force_rows == 0 && N >= 16384)) {
     gemv_bf16_kernel<4><<<(N + 15) / 16, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                                                      (const bf16_t*)residual, (bf16_t*)y, y_f32, N, K, act);
-  } else if (N >= 4096 || (long long)N * K >= (8LL << 20)) {      // enough rows, or rows long enough to want 2 per wave
+  } else if (force_rows == 2 || (force_rows == 0 && (N >= 4096 || (long long)N * K >= (8LL << 20)))) {      // enough rows, or rows long enough to want 2 per wave
     gemv_bf16_kernel<2><<<(N + 7) / 8, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                                                    (const bf16_t*)residual, (bf16_t*)y, y_f32, N, K, act);
   } else {
