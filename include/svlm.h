@@ -140,6 +140,20 @@ int svlm_rope_index(const int* ids, int L, const int* grids, int n_grids, int me
                     int* pos3, float* posf3, int stride, float second_per_grid_t, float tokens_per_second, int n_extra, void* ws,
                     long long ws_bytes, void* stream);
 
+/* Span finder + eviction policy on the device: one single-workgroup kernel over the device copy of the ids computes what
+ * the reference computes in Python per chunk -- every get_qwen_range (utils/get_qwen_range.py:15-86) the policy asks for, the policy
+ * itself (policy 1: process_past_kv, inference.py:87-172, round = chunk index; policy 0: BASELINE sink/window with the cut end
+ * snapped to <|vision_end|>) and the id edits (prune_id_and_kv_cache :50-61, resort_id_and_kv :100-108).
+ * ws (>= svlm_evict_plan_ws_bytes(L)) starts with int out[4 + 64]: status (0 ok, 1 a span the policy needs is missing, 2 more than
+ * 16 ops), n_ops, new length, result buffer (0: `ids` itself, 1: the int array at ws + (4 + 64) * 4), then n_ops x (1 = prune | 2 =
+ * move, start, end, dst): the eviction indices the host applies to the KV pool's slot table.  text_sink / text_sliding_window < 0
+ * mean None; tokens = HOST array {<|im_start|>, <|im_end|>, user, assistant, <|vision_start|>, <|vision_end|>, <|video_pad|>, "\n",
+ * previous, " text", Time} (get_qwen_range.py:2-13). */
+long long svlm_evict_plan_ws_bytes(int max_len);
+int svlm_evict_plan(int* ids, int L, int policy, int round, int text_round, int visual_round, int text_sink, int text_sliding_window,
+                    int assistant_start_bias, int assistant_end_bias, int sink, int window, int kv_len, const int* tokens, void* ws,
+                    long long ws_bytes, void* stream);
+
 /* Append T un-rotated K/V rows of one layer at logical rows base..base+T-1 (base = *len_dev or start).
  * replaces: StreamingCache.update = torch.cat (generate/streaming_cache.py:72-73). */
 int svlm_kv_append(const void* k_new, int k_stride, const void* v_new, int v_stride, void* k_planes, void* v_planes,

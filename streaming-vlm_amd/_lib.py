@@ -46,6 +46,8 @@ SIGNATURES = {
     "svlm_mrope_table": (_i, [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "svlm_rope_index_ws_bytes": (_ll, [_i, _i]),
     "svlm_rope_index": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _f, _f, _i, _p, _ll, _p]),
+    "svlm_evict_plan_ws_bytes": (_ll, [_i]),
+    "svlm_evict_plan": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _ll, _p]),
     "svlm_kv_append": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "svlm_kv_move_rows": (_i, [_p, _ll, _i, _i, _p, _p, _i, _p]),
     "svlm_kv_gather": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -161,6 +161,40 @@ def process_past_kv(past_key_values, i, text_round, visual_round, full_conversat
     return kv, ids, recent_video_window_clips, recent_pixel_values_videos
 
 
+def _history_edits(i, text_round, visual_round, hist, recent_video_window_clips, recent_pixel_values_videos):
+    """The part of process_past_kv (inference.py:87-172) that edits the conversation history and the retained clips, without the
+    index arithmetic: what is left for the host when the eviction indices come from the device (`apply_eviction_plan`)."""
+    if i >= text_round:
+        assert hist[0]["role"] == "previous text"
+        assert hist[-2 * text_round]["role"] == "user" and hist[-(2 * text_round - 1)]["role"] == "assistant"
+        hist[0]["content"] += hist[-(2 * text_round - 1)]["content"][:-4]
+        user_turn = hist[-2 * text_round]["content"]
+        for k, item in enumerate(user_turn):
+            if item["type"] == "text":
+                del user_turn[k]
+                break
+        del hist[-(2 * text_round - 1)]
+    if i >= visual_round:
+        recent_video_window_clips.pop(0)
+        recent_pixel_values_videos.pop(0)
+        if visual_round < text_round:
+            turn = hist[-2 * visual_round]
+            turn["content"] = [item for item in turn["content"] if item["type"] != "video"]
+    if i >= max(visual_round, text_round):
+        del hist[1]
+
+
+def apply_eviction_plan(ids, kv, ops, trace=None):
+    """Apply the op list of `svlm_evict_plan` (device-side span finder + policy) to the host ids and the KV pool: the
+    same prune / move calls, with the indices the device computed."""
+    for op in ops:
+        if op[0] == "prune":
+            ids, kv = prune_id_and_kv_cache(ids, kv, op[1], op[2], trace)
+        else:
+            ids, kv = resort_id_and_kv(ids, kv, op[1], op[2], op[3], trace)
+    return ids, kv
+
+
 # ----------------------------------------------------------------------------- loading
 def required_max_len(tokens_per_chunk, max_new_tokens=MAX_TOKEN_PER_DURATION, kv_policy="structural", window_size=DEFAULT_WINDOW_SIZE,
                      text_round=DEFAULT_TEXT_ROUND, text_sink=None, text_sliding_window=None, sink=4, window=2048, num_chunks=TOTAL_VIDEO_DURATION,
@@ -237,7 +271,7 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
                         max_new_tokens=MAX_TOKEN_PER_DURATION, suppress_eos=False, trace: Optional[List] = None,
                         token_counts: Optional[List] = None, ids_log: Optional[List] = None, video=None,
                         generator=None, keep_logits=False, chunk_callback=None, vision_lookahead=True, force_tokens=None,
-                        max_len=None, top_k=None, top_p=None, dense_prefill_chunks=0):
+                        max_len=None, top_k=None, top_p=None, dense_prefill_chunks=0, device_policy=False):
     # The reference synchronises the device around every section to print per-section times.  Nobody reads them when the
     # loop is quiet and not under time_test, and each of the dozen syncs per chunk is host time the GPU spends idle.
     timed_sections = time_test or not quiet
@@ -336,7 +370,24 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
 
         # ---- evict
         _sync(); _t = time.perf_counter()
-        if prev_generated_ids is not None:
+        if prev_generated_ids is not None and device_policy and kv_policy in ("structural", "sink_window"):
+            # f-1: spans and eviction indices from the device (svlm_evict_plan over the device copy of the ids); the host applies
+            # the op list to its id tensor and to the KV pool's slot table, and keeps the conversation-history strings
+            ops_dev = model._svlm_engine.ops
+            if kv_policy == "structural":
+                plan, _ = ops_dev.evict_plan(prev_generated_ids[0].tolist(), "structural", i, text_round, window_size, text_sink, text_sliding_window,
+                                             assistant_start_bias, assistant_end_bias, device=device)
+                _history_edits(i, text_round, window_size, full_conversation_history, recent_video_window_clips, recent_pixel_values_videos)
+            else:
+                plan, _ = ops_dev.evict_plan(prev_generated_ids[0].tolist(), "sink_window", sink=sink, window=window,
+                                             kv_len=past_key_values.get_seq_length(), device=device)
+                if len(recent_video_window_clips) >= window_size:
+                    recent_video_window_clips.pop(0)
+                    recent_pixel_values_videos.pop(0)
+            prev_generated_ids, past_key_values = apply_eviction_plan(prev_generated_ids, past_key_values, plan, chunk_trace)
+            if kv_policy == "structural" and i > 0:
+                prev_generated_ids, past_key_values = contiguous_id_and_kv(prev_generated_ids, past_key_values)
+        elif prev_generated_ids is not None:
             if kv_policy == "structural":
                 past_key_values, prev_generated_ids, recent_video_window_clips, recent_pixel_values_videos = process_past_kv(
                     past_key_values, i, text_round=text_round, visual_round=window_size,

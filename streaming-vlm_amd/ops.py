@@ -348,6 +348,36 @@ class HipOps:
                                        0 if is_f else _ptr(pos3), _ptr(pos3) if is_f else 0, pos3.shape[1], float(second_per_grid_t),
                                        float(tokens_per_second), int(n_extra), _ptr(ws), ws.numel() * 4, _stream()), "svlm_rope_index")
 
+    def evict_plan(self, ids, policy, round_i=0, text_round=16, visual_round=16, text_sink=None, text_sliding_window=None,
+                   assistant_start_bias=3, assistant_end_bias=2, sink=4, window=2048, kv_len=0, device="cuda"):
+        """Span finder + eviction policy on the device (svlm_evict_plan).  ids: host int sequence (uploaded here) -> (ops, new ids) with
+        ops = [("prune", s, e) | ("move", s, e, dst)], the reference's eviction indices in order.  One small D2H at the end."""
+        import ctypes
+        import numpy as np
+        from .spans import TOKEN_IDS
+        arr = np.asarray(ids, dtype=np.int32).reshape(-1)
+        L = int(arr.shape[0])
+        d_ids = torch.from_numpy(arr).to(device)
+        ws = torch.zeros((self.lib.svlm_evict_plan_ws_bytes(L) + 3) // 4, dtype=torch.int32, device=device)
+        pt = TOKEN_IDS["previous text"]
+        toks = (ctypes.c_int * 11)(TOKEN_IDS["<|im_start|>"], TOKEN_IDS["<|im_end|>"], TOKEN_IDS["user"], TOKEN_IDS["assistant"],
+                                   TOKEN_IDS["<|vision_start|>"], TOKEN_IDS["<|vision_end|>"], TOKEN_IDS["<|video_pad|>"], TOKEN_IDS["\n"],
+                                   pt[0], pt[1], TOKEN_IDS["Time"])
+        check(self.lib.svlm_evict_plan(_ptr(d_ids), L, {"sink_window": 0, "structural": 1}[policy], int(round_i), int(text_round), int(visual_round),
+                                       -1 if text_sink is None else int(text_sink), -1 if text_sliding_window is None else int(text_sliding_window),
+                                       int(assistant_start_bias), int(assistant_end_bias), int(sink), int(window), int(kv_len),
+                                       ctypes.cast(toks, ctypes.c_void_p), _ptr(ws), ws.numel() * 4, _stream()), "svlm_evict_plan")
+        out = ws[:68].cpu().numpy()
+        status, n_ops, new_len, which = int(out[0]), int(out[1]), int(out[2]), int(out[3])
+        if status:
+            raise _lib.SvlmError(f"svlm_evict_plan: status {status} (1: a span the policy needs is missing, 2: more than 16 edits)")
+        ops = []
+        for k in range(n_ops):
+            t, a, b, c = (int(v) for v in out[4 + 4 * k: 8 + 4 * k])
+            ops.append(("prune", a, b) if t == 1 else ("move", a, b, c))
+        res = (ws[68:68 + new_len] if which == 1 else d_ids[:new_len]).cpu().numpy().astype(np.int64)
+        return ops, res
+
     @staticmethod
     def _planes(pool, layer):
         # pool (layers, 2, Hkv, n_slots, D)

@@ -237,6 +237,66 @@ def test_golden_streams_eviction_trace_and_tokens():
         assert got == g["new_tokens"], (name, same)
 
 
+def test_golden_streams_with_the_device_side_eviction_plan():
+    """the same committed streams with the spans and eviction indices computed ON THE DEVICE (svlm_evict_plan: the
+    reference's get_qwen_range + process_past_kv / the sink-window cut as one kernel over the device copy of the ids) -- every
+    prune / move interval, KV length and token must again equal the oracle's."""
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "oracle_streams.json")) as f:
+        gold = json.load(f)
+    n_ops = 0
+    for name, g in gold.items():
+        kw = dict(g["kwargs"])
+        cfg, sd, model = _tiny_model(family="qwen2_5" if g.get("model") == "tiny_2_5" else "qwen2",
+                                     stream=dict(size=kw.get("size", 56), all_text=kw.get("all_text", False)))
+        _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], device_policy=True, **kw)
+        assert [[list(t) for t in c] for c in trace] == g["trace"], name
+        assert [e["kv_len"] for e in ids_log] == g["kv_len"], name
+        assert [e["new"] for e in ids_log] == g["new_tokens"], name
+        n_ops += sum(len(c) for c in trace)
+    print(f"[device policy] {len(gold)} streams, {n_ops} device-computed prune / move intervals identical to the oracle's")
+    assert n_ops > 100
+
+
+def test_evict_plan_kernel_edits_the_ids_like_the_host():
+    """svlm_evict_plan as a pure function: op list AND edited ids equal the host policy's on a hand-built history, incl. the
+    move of the assistant text, a vision span at the sink/window cut, and the no-op cases."""
+    import numpy as np
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd.ops import HipOps
+    from streaming_vlm_amd.driver import process_past_kv, sink_window_evict
+    o = HipOps()
+    IM_S, IM_E, U, A, VS, VE, VP, LF, TIME = 151644, 151645, 872, 77091, 151652, 151653, 151656, 198, 1462
+    sys_ = [IM_S, 8948, LF, 2610, 525, 264, 10950, 17847, 13, IM_E, LF]
+    prev = [IM_S, 19702, 1467, LF] + list(range(300, 330)) + [IM_E, LF]
+    def user(n, q=()): return [IM_S, U, LF, TIME, 28, 15, 13, 15, 82, VS] + [VP] * n + [VE] + list(q) + [IM_E, LF]
+    def asst(t): return [IM_S, A, LF] + list(t) + [2503, IM_E, LF]
+    ids = sys_ + prev
+    for r in range(5):
+        ids = ids + user(6, q=[900, 901] if r == 0 else ()) + asst([40 + r, 50 + r, 60 + r])
+    ids = ids[:-1]                                           # the history ends with <|im_end|>
+    for rnd, tr, vr, ts, tsw in [(5, 2, 3, 4, 8), (5, 3, 2, 2, 6), (5, 4, 4, None, None), (1, 4, 4, 4, 8), (0, 2, 2, 4, 8), (5, 2, 2, None, 10)]:
+        t = torch.tensor([ids])
+        hist = [{"role": "previous text", "content": "x"}] + [{"role": "user" if k % 2 == 0 else "assistant", "content": [{"type": "text", "text": "t"}, {"type": "video"}] if k % 2 == 0 else "abcd ..."} for k in range(10)]
+        trace = []
+        _, want_ids, _, _ = process_past_kv(None, rnd, tr, vr, hist, t, 3, 2, [0] * 8, [0] * 8, ts, tsw, trace)
+        ops, got_ids = o.evict_plan(ids, "structural", rnd, tr, vr, ts, tsw, 3, 2)
+        assert [tuple(x) for x in ops] == [tuple(x) for x in trace], (rnd, tr, vr, ops, trace)
+        assert np.array_equal(got_ids, want_ids[0].numpy()), (rnd, tr, vr)
+    for sink, window in [(4, 40), (4, 37), (4, 200), (0, 10), (4, 33)]:
+        trace = []
+        class KV:          # the host function only asks for the length
+            def __init__(self, n): self.n = n
+            def get_seq_length(self): return self.n
+            def release_reserved(self): pass
+            def prune(self, s, e): self.n -= e - s + 1
+        kv = KV(len(ids) - 1)
+        _, want_ids = sink_window_evict(kv, torch.tensor([ids]), sink, window, trace)
+        ops, got_ids = o.evict_plan(ids, "sink_window", sink=sink, window=window, kv_len=len(ids) - 1)
+        assert [tuple(x) for x in ops] == [tuple(x) for x in trace], (sink, window, ops, trace)
+        assert np.array_equal(got_ids, want_ids[0].numpy()), (sink, window)
+
+
 def test_golden_full_size_streams_tokens_exact():
     """Full-size models against token streams minted by the CPU oracle in the build container (tests/golden/
     full_size_streams.json): BASELINE configs[1] -- Qwen2-VL-2B, 448x448 @1 fps, sink 4 / window 2048, 20 tokens per chunk,
