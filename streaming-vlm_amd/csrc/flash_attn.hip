@@ -25,14 +25,15 @@
 // computed (two iterations to land), one barrier per 32-key tile.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define FA_KT 32        // keys per tile
 #define FA_VLD 144      // V LDS row stride (bf16): 288 B = 8 banks (mod 64) per key -> conflict-free ds_read_b64_tr_b16
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 #define FA_THREADS 256
 
-template <int D, int DP, int NG>
-__global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
+template <int D, int DP, int NG, int QB = 1>
+__global__ __launch_bounds__(256 * NG) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 2 : 3))) void flash_attn_kernel(
     const bf16_t* __restrict__ q, long q_row_stride, long q_head_stride, long q_seq_stride,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long kv_row_stride, long kv_head_stride, long kv_seq_stride,
     bf16_t* __restrict__ out, long o_row_stride, long o_head_stride, long o_seq_stride,
@@ -45,7 +46,11 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
   // NG wave groups of 4 waves: every group serves the SAME 64 queries and takes one 32-key sub-tile of each staged
   // "super tile" of ST = 32 * NG keys, so that two waves share a SIMD and hide each other's LDS / exp latency (the ViT's 256
   // workgroups are one per CU).  The groups' (m, l, O) are merged through LDS at the end.
-  constexpr int THREADS = 256 * NG, ST = FA_KT * NG;
+  // QB query blocks of 16 rows per wave (long prefills: QB = 2): every K / V^T fragment read from LDS feeds QB MFMAs, so the LDS
+  // bytes per flop -- what bounds the one-block kernel, 1 KB per 16-cycle MFMA on each of the four SIMDs = the whole 256 B/clk of
+  // the LDS -- fall by QB.
+  static_assert(NG == 1 || QB == 1, "wave groups and query blocks are alternatives");
+  constexpr int THREADS = 256 * NG, ST = FA_KT * NG, QROWS = 64 * QB;
   constexpr int NCH = (ST * CPR + THREADS - 1) / THREADS;   // chunks staged per thread per super tile
   constexpr int KS_STAGE = ST * KLD, VT_STAGE = ST * FA_VLD;
   extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
@@ -53,14 +58,14 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
   bf16_t* Vt = Ks + 2 * KS_STAGE;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
+  const int lane = tid & 63, wave = (tid >> 6) & 3, grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 8);      // grp: wave-uniform
   const int fr = lane & 15, fq = lane >> 4;
   // n_split > 1 (prefill only, one sequence): blockIdx.z is the key split; each split covers an even number of this
   // workgroup's key tiles and leaves un-normalised (O, m, l) partials for flash_combine_kernel
   const int seq = n_split > 1 ? 0 : blockIdx.z, head = blockIdx.y;
   const int sp = n_split > 1 ? blockIdx.z : 0;
   const int kvh = head / (Hq / Hkv);
-  const int qbase = (blockIdx.x * 4 + wave) * 16;
+  const int qbase = (blockIdx.x * 4 + wave) * 16 * QB;
   q += seq * q_seq_stride;
   k += seq * kv_seq_stride + kvh * kv_head_stride;
   v += seq * kv_seq_stride + kvh * kv_head_stride;
@@ -75,131 +80,156 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
   }
 
   // ---- Q fragments (B operand): lane (fr, fq) holds Q[qbase+fr][ks*32 + fq*8 .. +7]
-  const int tq = qbase + fr;
-  const int tq_c = tq < T ? tq : T - 1;
-  bf16x8_t qf[NKS];
-  {
-    const bf16_t* qr = q + (size_t)tq_c * q_row_stride + (size_t)head * q_head_stride;
+  bf16x8_t qf[QB][NKS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = qbase + qb * 16 + fr;
+    const bf16_t* qr = q + (size_t)(tq < T ? tq : T - 1) * q_row_stride + (size_t)head * q_head_stride;
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int d0 = ks * 32 + fq * 8;
       u32x4_t raw = d0 < D ? *reinterpret_cast<const u32x4_t*>(qr + d0) : u32x4_t{0, 0, 0, 0};
-      qf[ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+      qf[qb][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
     }
   }
 
-  f32x4_t oacc[NDT];
+  f32x4_t oacc[QB][NDT];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[qb][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    m_run[qb] = -1e30f;
+    l_run[qb] = 0.f;
+  }
   const float cexp = scale * 1.4426950408889634f;      // scale * log2(e)
 
   // keys needed by this workgroup
   int kmax = L;
-  if (causal) kmax = min(L, min(blockIdx.x * 64 + 63, T - 1) + causal_offset + 1);
+  if (causal) kmax = min(L, min((int)blockIdx.x * QROWS + QROWS - 1, T - 1) + causal_offset + 1);
   const int n_kt_all = (kmax + ST - 1) / ST;          // in super tiles
   const int per = ((n_kt_all + n_split - 1) / n_split + 1) & ~1;      // even: the stage parity below starts at 0
   const int kt_lo = sp * per;
   const int n_kt = min(n_kt_all, kt_lo + per);
 
   // ---- staging: thread owns chunks idx = tid + i*256 of every tile; two register slots form a ring so that the
-  // global loads of tile t+3 are in flight while tile t is computed (one barrier per tile, two iterations to land)
+  // global loads of tile t+3 are in flight while tile t is computed (one barrier per tile, two iterations to land).
+  // K and V come through buffer descriptors: the per-thread byte offset is loop-invariant, the tile's offset is ONE scalar, and
+  // the range check of the descriptor returns zeros for rows >= L and for tiles past the end -- no address arithmetic, clamping
+  // or zero-fill selects in the loop.
+  const unsigned kv_bytes = ((unsigned)(L - 1) * (unsigned)kv_row_stride + D) * 2u;
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(k), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(v), 0, kv_bytes, 0x00020000);
+  const unsigned tile_bytes = (unsigned)ST * (unsigned)kv_row_stride * 2u;
+  unsigned voff[NCH], lds_k[NCH], lds_v[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int idx = tid + i * THREADS;
+    const int row = idx / CPR, c = idx % CPR;
+    voff[i] = idx < ST * CPR ? ((unsigned)row * (unsigned)kv_row_stride + c * 8) * 2u : 0xFFFFFFF0u;       // beyond the tile: out of range
+    lds_k[i] = row * KLD + c * 8;
+    lds_v[i] = row * FA_VLD + c * 8;
+  }
   u32x4_t kr0[NCH], vr0[NCH], kr1[NCH], vr1[NCH];
   auto load_tile = [&](int kt, u32x4_t (&kreg)[NCH], u32x4_t (&vreg)[NCH]) {
+    const unsigned soff = (unsigned)kt * tile_bytes;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int idx = tid + i * THREADS;
-      const int row = idx / CPR, c = idx % CPR;
-      // unconditional loads from clamped addresses + select (predicated loads become branches and make hipcc drain the
-      // register ring with vmcnt(0))
-      const int j = kt * ST + (idx < ST * CPR ? row : 0);
-      const size_t off = (size_t)min(j, L - 1) * kv_row_stride + (idx < ST * CPR ? c : 0) * 8;
-      kreg[i] = *reinterpret_cast<const u32x4_t*>(k + off);       // rows >= L are zeroed when the tile is stored
-      vreg[i] = *reinterpret_cast<const u32x4_t*>(v + off);
+      const unsigned off = voff[i] + soff;             // the tile offset rides in the VGPR offset, which the range check is certain to cover
+      const auto kk = __builtin_amdgcn_raw_buffer_load_b128(k_rs, off, 0, 0);
+      const auto vv = __builtin_amdgcn_raw_buffer_load_b128(v_rs, off, 0, 0);
+      kreg[i] = u32x4_t{kk[0], kk[1], kk[2], kk[3]};
+      vreg[i] = u32x4_t{vv[0], vv[1], vv[2], vv[3]};
     }
   };
   auto store_tile = [&](int st, int kt, const u32x4_t (&kreg)[NCH], const u32x4_t (&vreg)[NCH]) {
     bf16_t* ks_ = Ks + st * KS_STAGE;
     bf16_t* vt_ = Vt + st * VT_STAGE;
-    const u32x4_t z = u32x4_t{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int idx = tid + i * THREADS;
-      if (idx < ST * CPR) {
-        const int row = idx / CPR, c = idx % CPR;
-        const bool ok = kt * ST + row < L;            // only the tile that crosses L zeroes anything
-        *reinterpret_cast<u32x4_t*>(ks_ + row * KLD + c * 8) = ok ? kreg[i] : z;
-        *reinterpret_cast<u32x4_t*>(vt_ + row * FA_VLD + c * 8) = ok ? vreg[i] : z;      // V stays row-major: transposed on read
+      if ((NCH * THREADS == ST * CPR) || tid + i * THREADS < ST * CPR) {
+        *reinterpret_cast<u32x4_t*>(ks_ + lds_k[i]) = kreg[i];
+        *reinterpret_cast<u32x4_t*>(vt_ + lds_v[i]) = vreg[i];      // V stays row-major: transposed on read
       }
     }
   };
 
-  auto compute = [&](int kt, int st) {
+  // MASK = false is the straight-line body of every tile below the causal diagonal and inside the sequence (almost all of a long
+  // prefill); the variant is picked per wave by a scalar branch, so the common body carries no predicate bookkeeping at all
+  const int qbase_s = __builtin_amdgcn_readfirstlane(qbase);
+  auto compute_t = [&](int kt, int st, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const bf16_t* ks_ = Ks + st * KS_STAGE + grp * (FA_KT * KLD);        // this wave group's 32 keys of the super tile
     const bf16_t* vt_ = Vt + st * VT_STAGE + grp * (FA_KT * FA_VLD);
     const int j0 = kt * ST + grp * FA_KT;
-    // ---- S^T = K . Q^T   (two 16-key sub-tiles)
-    f32x4_t sacc[2];
+    // ---- S^T = K . Q^T   (two 16-key sub-tiles; each K fragment serves the wave's QB query blocks)
+    f32x4_t sacc[QB][2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      sacc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) sacc[qb][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ks_ + (sub * 16 + fr) * KLD + ks * 32 + fq * 8);
-        sacc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], sacc[sub], 0, 0, 0);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qb][ks], sacc[qb][sub], 0, 0, 0);
       }
     }
     // ---- online softmax for query column fr; this lane holds keys kt*32 + sub*16 + 4*fq + r.
-    // Scores stay un-scaled until the exponent: p = exp2(s*c - m*c), c = scale*log2(e) (one FMA + v_exp per score).
-    // Masking runs only on tiles that touch the sequence end or the causal diagonal (wave-uniform test).
-    float sv[8];
+    // Scores are scaled into the exponent's unit first (t = s * scale*log2 e: a plain VALU product, which also spares the
+    // canonicalising v_max hipcc puts in front of an fmaxf on raw MFMA outputs), p = exp2(t - m) is one subtraction + one bare
+    // v_exp_f32 per score (exp2f() costs seven instructions for its denormal range), and the row sum stays a per-lane partial
+    // until the epilogue (the rescale factor is the same in the four lanes of a query).  m_run is kept in the scaled unit.
+    // Masking runs only on tiles that touch the sequence end or the causal diagonal.
+    bf16x8_t pb[QB];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int qb = 0; qb < QB; ++qb) {
+      const int tq = qbase + qb * 16 + fr;
+      float sv[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sv[sub * 4 + r] = sacc[sub][r];
-    const int j_hi = j0 + FA_KT - 1;
-    const bool need_mask = j_hi >= L || (causal && j_hi > qbase + causal_offset);      // qbase = smallest query of the wave
-    unsigned okbits = 0xFFu;
-    if (need_mask) {
-      okbits = 0;
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[sub * 4 + r] = sacc[qb][sub][r] * cexp;
+      unsigned okbits = 0xFFu;
+      if constexpr (MASK) {
+        okbits = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = j0 + (i >> 2) * 16 + fq * 4 + (i & 3);
+          const bool ok = j < L && (!causal || j <= tq + causal_offset);
+          sv[i] = ok ? sv[i] : -1e30f;
+          okbits |= ok ? (1u << i) : 0u;
+        }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+      mx = xor32_max(xor16_max(mx));
+      const float m_new = fmaxf(m_run[qb], mx);               // running max of the scaled scores
+      float p[8], rs = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = j0 + (i >> 2) * 16 + fq * 4 + (i & 3);
-        const bool ok = j < L && (!causal || j <= tq + causal_offset);
-        sv[i] = ok ? sv[i] : -1e30f;
-        okbits |= ok ? (1u << i) : 0u;
+        p[i] = __builtin_amdgcn_exp2f(sv[i] - m_new);     // masked scores (-1e30) underflow to exactly 0 ...
       }
-    }
-    float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-    mx = xor32_max(xor16_max(mx));
-    const float m_new = fmaxf(m_run, mx);               // running max of the RAW scores
-    const float mc = m_new * cexp;
-    float p[8], rs = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      p[i] = exp2f(fmaf(sv[i], cexp, -mc));              // masked scores (-1e30) underflow to exactly 0 ...
-    }
-    if (need_mask) {                                     // ... unless the whole row is masked so far (a key split that
+      if constexpr (MASK) {                                // ... unless the whole row is masked so far (a key split that
 #pragma unroll                                           // starts beyond a query's causal limit): m is still -1e30 there
-      for (int i = 0; i < 8; ++i) p[i] = (okbits >> i) & 1u ? p[i] : 0.f;
+        for (int i = 0; i < 8; ++i) p[i] = (okbits >> i) & 1u ? p[i] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rs += p[i];
+      // rescale only when some query of the wave saw a new maximum (rare after the first tiles)
+      const bool grew = m_new > m_run[qb];
+      float alpha = 1.f;
+      if (__any(grew)) {
+        alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) oacc[qb][dt][r] *= alpha;
+      }
+      l_run[qb] = l_run[qb] * alpha + rs;                  // this lane's 8 keys of every tile; summed over the query's 4 lanes at the end
+      m_run[qb] = m_new;
+      u32x4_t pk = pack8(p);
+      pb[qb] = *reinterpret_cast<bf16x8_t*>(&pk);
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rs += p[i];
-    rs = xor32_sum(xor16_sum(rs));
-    // rescale only when some query of the wave saw a new maximum (rare after the first tiles)
-    const bool grew = m_new > m_run;
-    float alpha = 1.f;
-    if (__any(grew)) {
-      alpha = exp2f((m_run - m_new) * cexp);
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-    }
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-    u32x4_t pk = pack8(p);
-    const bf16x8_t pb = *reinterpret_cast<bf16x8_t*>(&pk);
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
@@ -209,8 +239,14 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
       const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr));
       const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr + 16 * FA_VLD));
       const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[qb], oacc[qb][dt], 0, 0, 0);
     }
+  };
+  auto compute = [&](int kt, int st) {
+    const int j_hi = __builtin_amdgcn_readfirstlane(kt * ST + grp * FA_KT + FA_KT - 1);
+    if (j_hi >= L || (causal && j_hi > qbase_s + causal_offset)) compute_t(kt, st, std::true_type{});       // qbase: smallest query of the wave
+    else compute_t(kt, st, std::false_type{});
   };
 
   load_tile(kt_lo, kr0, vr0);
@@ -235,6 +271,9 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
     lds_barrier();
   }
 
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) l_run[qb] = xor32_sum(xor16_sum(l_run[qb]));
+
   // ---- merge of the wave groups: group g > 0 leaves (m, l, O) in the (now idle) staging LDS, group 0 folds them in
   if constexpr (NG > 1) {
     float* mg = reinterpret_cast<float*>(fa_smem);
@@ -246,21 +285,21 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mg[(dt * 4 + r) * 256 + t256] = oacc[dt][r];
-        mg[(NDT * 4) * 256 + t256] = m_run;
-        mg[(NDT * 4 + 1) * 256 + t256] = l_run;
+          for (int r = 0; r < 4; ++r) mg[(dt * 4 + r) * 256 + t256] = oacc[0][dt][r];
+        mg[(NDT * 4) * 256 + t256] = m_run[0];
+        mg[(NDT * 4 + 1) * 256 + t256] = l_run[0];
       }
       __syncthreads();
       if (grp == 0) {
         const float m1 = mg[(NDT * 4) * 256 + t256], l1 = mg[(NDT * 4 + 1) * 256 + t256];
-        const float M = fmaxf(m_run, m1);
-        const float a0 = exp2f((m_run - M) * cexp), a1 = exp2f((m1 - M) * cexp);
+        const float M = fmaxf(m_run[0], m1);
+        const float a0 = exp2f(m_run[0] - M), a1 = exp2f(m1 - M);
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) oacc[dt][r] = oacc[dt][r] * a0 + mg[(dt * 4 + r) * 256 + t256] * a1;
-        l_run = l_run * a0 + l1 * a1;
-        m_run = M;
+          for (int r = 0; r < 4; ++r) oacc[0][dt][r] = oacc[0][dt][r] * a0 + mg[(dt * 4 + r) * 256 + t256] * a1;
+        l_run[0] = l_run[0] * a0 + l1 * a1;
+        m_run[0] = M;
       }
       if (g + 1 < NG) __syncthreads();
     }
@@ -269,27 +308,258 @@ __global__ __launch_bounds__(256 * NG) void flash_attn_kernel(
   }
 
   // ---- epilogue: lane holds O[tq][dt*16 + 4*fq + r]
-  if (n_split > 1) {
-    if (tq < T) {
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = qbase + qb * 16 + fr;
+    if (tq >= T) continue;
+    if (n_split > 1) {
       const size_t row = ((size_t)sp * T + tq) * Hq + head;
       float* po = part_o + row * D;
 #pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<f32x4_t*>(po + dt * 16 + fq * 4) = oacc[dt];
+      for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<f32x4_t*>(po + dt * 16 + fq * 4) = oacc[qb][dt];
       if (fq == 0) {
-        part_ml[row * 2] = m_run;
-        part_ml[row * 2 + 1] = l_run;
+        part_ml[row * 2] = m_run[qb];
+        part_ml[row * 2 + 1] = l_run[qb];
       }
+      continue;
     }
-    return;
-  }
-  if (tq < T) {
-    const float inv = 1.0f / l_run;
+    const float inv = 1.0f / l_run[qb];
     bf16_t* orow = out + (size_t)tq * o_row_stride + (size_t)head * o_head_stride;
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
       u32x2_t o;
-      o[0] = pack2(oacc[dt][0] * inv, oacc[dt][1] * inv);
-      o[1] = pack2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+      o[0] = pack2(oacc[qb][dt][0] * inv, oacc[qb][dt][1] * inv);
+      o[1] = pack2(oacc[qb][dt][2] * inv, oacc[qb][dt][3] * inv);
+      *reinterpret_cast<u32x2_t*>(orow + dt * 16 + fq * 4) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LLM prefill, d = 128: the same products and softmax with K and V staged by LDS-DMA (`buffer_load_dwordx4 ... lds`) instead of
+// through a register ring: no staging registers, no ds_write pass, and the descriptor's range check zero-fills rows >= L.
+// A DMA piece lands lane-linear (lane i -> base + 16 i: 4 rows of 256 B), so rows cannot be padded; bank conflicts are avoided by
+// XOR-swizzling the 16-B chunks of a row through the per-lane SOURCE offset and again on the fragment reads:
+//   K (ds_read_b128, lane = (key fr, chunk 4 ks + fq)):                  chunk ^ (key & 15)
+//   V (ds_read_b64_tr_b16, lane = (key 4 fq + fr/4, 8-B piece fr % 4)):   chunk ^ ((key & 7) << 1)
+// both conflict-free for the lane groups the LDS serves together.  Three 16 KB stages (tile t+2 in flight while tile t is
+// computed), counted vmcnt + raw s_barrier, the ring unrolled by three so that every LDS address is a per-lane register plus an
+// immediate.  QB query blocks of 16 rows per wave as in flash_attn_kernel.
+#define PA_TILE_B (FA_KT * 256)
+#define PA_STAGE_B (2 * PA_TILE_B)
+template <int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 2 : 3))) void prefill_attn_dma_kernel(
+    const bf16_t* __restrict__ q, long q_row_stride, long q_head_stride, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    long kv_head_stride, bf16_t* __restrict__ out, long o_row_stride, long o_head_stride, int T, int L, int causal_offset, int Hq,
+    int Hkv, float scale, int n_split, float* __restrict__ part_o, float* __restrict__ part_ml) {
+  constexpr int D = 128, NKS = 4, NDT = 8, QROWS = 64 * QB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int head = blockIdx.y, sp = n_split > 1 ? blockIdx.z : 0;
+  const int kvh = head / (Hq / Hkv);
+  const int qbase = (blockIdx.x * 4 + wave) * 16 * QB;
+  k += kvh * kv_head_stride;
+  v += kvh * kv_head_stride;
+
+  bf16x8_t qf[QB][NKS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int tq = qbase + qb * 16 + fr;
+    const bf16_t* qr = q + (size_t)(tq < T ? tq : T - 1) * q_row_stride + (size_t)head * q_head_stride;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qr + ks * 32 + fq * 8);
+      qf[qb][ks] = *reinterpret_cast<bf16x8_t*>(&raw);
+    }
+  }
+  f32x4_t oacc[QB][NDT];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) oacc[qb][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    m_run[qb] = -1e30f;
+    l_run[qb] = 0.f;
+  }
+  const float cexp = scale * 1.4426950408889634f;
+
+  const int kmax = min(L, min((int)blockIdx.x * QROWS + QROWS - 1, T - 1) + causal_offset + 1);
+  const int n_kt_all = (kmax + FA_KT - 1) / FA_KT;
+  const int per = ((n_kt_all + n_split - 1) / n_split + 1) & ~1;
+  const int kt_lo = sp * per;
+  const int n_kt = min(n_kt_all, kt_lo + per);
+
+  // ---- DMA: wave w fills rows 8 w .. 8 w + 7 of the K and of the V tile, two 1-KiB pieces each
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(k), 0, L * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(v), 0, L * 256, 0x00020000);
+  // piece 1 holds the rows 4 below piece 0: its swizzle differs in one bit (K: chunk ^ 4, V: chunk ^ 8), so one source offset per
+  // operand is kept and the other derived (two query blocks per wave leave no register to spare)
+  unsigned src_k0, src_v0;
+  {
+    const int r = wave * 8 + (lane >> 4), pch = lane & 15;
+    src_k0 = r * 256 + ((pch ^ (r & 15)) * 16);
+    src_v0 = r * 256 + ((pch ^ ((r & 7) << 1)) * 16);
+  }
+  auto issue = [&](int kt, int stage) {
+    const unsigned tb = (unsigned)kt * PA_TILE_B;          // rides in the VGPR offset, which the range check is certain to cover
+    unsigned char* sk = fa_smem + stage * PA_STAGE_B + wave * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (__attribute__((address_space(3))) void*)(sk), 16, src_k0 + tb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (__attribute__((address_space(3))) void*)(sk + PA_TILE_B), 16, src_v0 + tb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, (__attribute__((address_space(3))) void*)(sk + 1024), 16, ((src_k0 + 1024) ^ 64u) + tb, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, (__attribute__((address_space(3))) void*)(sk + PA_TILE_B + 1024), 16, ((src_v0 + 1024) ^ 128u) + tb, 0, 0, 0);
+  };
+
+  // ---- per-lane LDS read offsets (stage and sub-tile offsets are immediates)
+  // K chunk of k-step ks: (4 ks + fq) ^ fr = (ks << 2) ^ (fq ^ fr) -> byte offset k_base ^ (ks << 6); V likewise v_base ^ (dt << 5)
+  unsigned k_base, v_base;
+  {
+    k_base = fr * 256 + ((fq ^ fr) * 16);
+    const int key = fq * 4 + (fr >> 2);
+    const int xk = ((key & 7) << 1) ^ ((fr & 3) >> 1);
+    v_base = PA_TILE_B + key * 256 + xk * 16 + (fr & 1) * 8;
+  }
+  const int qbase_s = __builtin_amdgcn_readfirstlane(qbase);
+
+  // The tile's tail comes in two variants picked by a scalar branch once the scores are known: RESCALE = false when no query of
+  // the wave saw a new maximum (nearly every tile after the first few: no alpha, no pass over the accumulators), RESCALE = true
+  // multiplies unconditionally.  (A conditional rescale INSIDE one body makes hipcc merge the accumulator tuples of both paths
+  // through copies: 256 VGPRs plus scratch at two query blocks per wave, against 165 for either variant alone.)
+  auto compute_t = [&](int kt, auto stage_c, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    constexpr int SB = decltype(stage_c)::value * PA_STAGE_B;
+    const unsigned char* st = fa_smem + SB;
+    const int j0 = kt * FA_KT;
+    f32x4_t sacc[QB][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) sacc[qb][sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(st + (k_base ^ (ks << 6)) + sub * 4096);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qb][ks], sacc[qb][sub], 0, 0, 0);
+      }
+    }
+    float sv[QB][8], m_new[QB];
+    unsigned okbits[QB];
+    bool grew = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int tq = qbase + qb * 16 + fr;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[qb][sub * 4 + r] = sacc[qb][sub][r] * cexp;
+      okbits[qb] = 0xFFu;
+      if constexpr (MASK) {
+        okbits[qb] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int j = j0 + (i >> 2) * 16 + fq * 4 + (i & 3);
+          const bool ok = j < L && j <= tq + causal_offset;
+          sv[qb][i] = ok ? sv[qb][i] : -1e30f;
+          okbits[qb] |= ok ? (1u << i) : 0u;
+        }
+      }
+      float mx = fmaxf(fmaxf(fmaxf(sv[qb][0], sv[qb][1]), fmaxf(sv[qb][2], sv[qb][3])),
+                       fmaxf(fmaxf(sv[qb][4], sv[qb][5]), fmaxf(sv[qb][6], sv[qb][7])));
+      mx = xor32_max(xor16_max(mx));
+      m_new[qb] = fmaxf(m_run[qb], mx);
+      grew = grew || m_new[qb] > m_run[qb];
+    }
+    auto finish = [&](auto rescale_tag) {
+      constexpr bool RESCALE = decltype(rescale_tag)::value;
+      bf16x8_t pb[QB];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float p[8], rs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sv[qb][i] - m_new[qb]);     // masked scores (-1e30) underflow to 0 ...
+        if constexpr (MASK) {                                // ... unless the whole row is masked so far (m still -1e30)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) p[i] = (okbits[qb] >> i) & 1u ? p[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rs += p[i];
+        if constexpr (RESCALE) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new[qb]);
+#pragma unroll
+          for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[qb][dt][r] *= alpha;
+          l_run[qb] = l_run[qb] * alpha + rs;               // this lane's 8 keys of every tile; summed over the query's 4 lanes at the end
+          m_run[qb] = m_new[qb];
+        } else {
+          l_run[qb] += rs;
+        }
+        u32x4_t pk = pack8(p);
+        pb[qb] = *reinterpret_cast<bf16x8_t*>(&pk);
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(st + (v_base ^ (dt << 5))));
+        const v4s_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(st + (v_base ^ (dt << 5)) + 4096));
+        const bf16x8_t a = bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[qb], oacc[qb][dt], 0, 0, 0);
+      }
+    };
+    if constexpr (MASK) {
+      finish(std::true_type{});
+    } else {
+      if (__any(grew)) finish(std::true_type{});
+      else finish(std::false_type{});
+    }
+  };
+  auto step = [&](int kt, auto stage_c) {
+    constexpr int S = decltype(stage_c)::value;
+    // tile kt has landed once at most the NEWER tile's four pieces of this wave are outstanding; behind the barrier everyone is
+    // past compute(kt - 1), whose stage (S + 2) % 3 may be refilled
+    if (kt + 1 < n_kt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kt + 2 < n_kt) issue(kt + 2, (S + 2) % 3);
+    const int j_hi = kt * FA_KT + FA_KT - 1;
+    if (j_hi >= L || j_hi > qbase_s + causal_offset) compute_t(kt, stage_c, std::true_type{});
+    else compute_t(kt, stage_c, std::false_type{});
+  };
+
+  if (kt_lo < n_kt) issue(kt_lo, 0);
+  if (kt_lo + 1 < n_kt) issue(kt_lo + 1, 1);
+  for (int kt = kt_lo; kt < n_kt;) {
+    step(kt, std::integral_constant<int, 0>{});
+    if (++kt >= n_kt) break;
+    step(kt, std::integral_constant<int, 1>{});
+    if (++kt >= n_kt) break;
+    step(kt, std::integral_constant<int, 2>{});
+    ++kt;
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l = xor32_sum(xor16_sum(l_run[qb]));
+    const int tq = qbase + qb * 16 + fr;
+    if (tq >= T) continue;
+    if (n_split > 1) {
+      const size_t row = ((size_t)sp * T + tq) * Hq + head;
+      float* po = part_o + row * D;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) *reinterpret_cast<f32x4_t*>(po + dt * 16 + fq * 4) = oacc[qb][dt];
+      if (fq == 0) {
+        part_ml[row * 2] = m_run[qb];
+        part_ml[row * 2 + 1] = l;
+      }
+      continue;
+    }
+    const float inv = 1.0f / l;
+    bf16_t* orow = out + (size_t)tq * o_row_stride + (size_t)head * o_head_stride;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      u32x2_t o;
+      o[0] = pack2(oacc[qb][dt][0] * inv, oacc[qb][dt][1] * inv);
+      o[1] = pack2(oacc[qb][dt][2] * inv, oacc[qb][dt][3] * inv);
       *reinterpret_cast<u32x2_t*>(orow + dt * 16 + fq * 4) = o;
     }
   }
@@ -300,11 +570,11 @@ static int fa_smem_bytes() {
   return 2 * (FA_KT * NG * (DP + 8) + FA_KT * NG * FA_VLD) * 2;
 }
 // Sets the dynamic-LDS limit once per instantiation (> 64 KB for two wave groups at d = 128).
-template <int D, int DP, int NG>
+template <int D, int DP, int NG, int QB = 1>
 static void fa_prepare() {
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D, DP, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_attn_kernel<D, DP, NG, QB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         fa_smem_bytes<D, DP, NG>());
     done = true;
   }
@@ -315,7 +585,7 @@ static int fa_groups(const char* env, int dflt) {
   return v == 2 ? 2 : 1;
 }
 
-// Merge of the key splits: out[t][h][:] = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2((m_s - max_s m_s) * scale*log2 e).
+// Merge of the key splits: out[t][h][:] = sum_s w_s O_s / sum_s w_s l_s,  w_s = exp2(m_s - max_s m_s), m_s = max score * scale*log2 e.
 // One thread per (t, h, 4 consecutive d).
 __global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                             bf16_t* __restrict__ out, long o_row_stride, int T, int Hq, int n_split,
@@ -325,7 +595,6 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restr
   if (i >= (long)T * Hq * (D / 4)) return;
   const int c = (int)(i % (D / 4));
   const long th = i / (D / 4);                       // t * Hq + h
-  const float cexp = scale * 1.4426950408889634f;
   float m[8], l[8];
   f32x4_t o[8];
   float M = -1e30f;
@@ -344,7 +613,7 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restr
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     if (s < n_split) {
-      const float w = exp2f((m[s] - M) * cexp);      // an empty split has l = 0 and O = 0
+      const float w = exp2f(m[s] - M);               // m comes in the exponent's unit; an empty split has l = 0 and O = 0
       Ls += w * l[s];
       acc += o[s] * w;
     }
@@ -453,6 +722,7 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   SVLM_CHECK_ARG(T >= 0 && L >= T && n_slots > 0, "svlm_prefill_attn_ropeload: need 0 <= T=%d <= L=%d", T, L);
   SVLM_CHECK_ARG(q_stride % 8 == 0 && o_stride % 4 == 0, "svlm_prefill_attn_ropeload: strides must keep 16-B alignment");
   SVLM_CHECK_ARG(ws != nullptr && ws_bytes >= svlm_prefill_attn_ws_bytes(T, L, Hq, Hkv), "svlm_prefill_attn_ropeload: workspace too small (%lld B)", ws_bytes);
+  SVLM_CHECK_ARG((long long)(L + 256) * 256 < (1LL << 31), "svlm_prefill_attn_ropeload: L=%d exceeds the 32-bit buffer offsets of the attention kernel", L);
   if (T == 0) return SVLM_OK;
   hipStream_t st = (hipStream_t)stream;
   bf16_t* q_rot = (bf16_t*)ws;
@@ -469,8 +739,39 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   const int ns = prefill_splits(T, L, Hq);
   float* part_o = (float*)(v_lin + (size_t)Hkv * L * 128);
   float* part_ml = part_o + (size_t)ns * T * Hq * 128;
-  dim3 grid((T + 63) / 64, Hq, ns);
   static const int ng = fa_groups("SVLM_PREFILL_FA_GROUPS", 1);
+  // long prefills (the dense-frame forward of configs[4]: 4096-row passes over up to 83k keys) run two query blocks per wave;
+  // a streaming chunk (T ~ 290) keeps the 64-row tiles, whose key splits fill the chip
+  static const int qb_env = getenv("SVLM_PREFILL_QB") ? atoi(getenv("SVLM_PREFILL_QB")) : 0;
+  const int qb = qb_env > 0 ? qb_env : (T >= 1024 && ns == 1 ? 2 : 1);
+  static const bool use_dma = getenv("SVLM_PREFILL_NO_DMA") == nullptr;
+  if (use_dma && ng != 2) {
+    dim3 gridd((T + 64 * qb - 1) / (64 * qb), Hq, ns);
+    if (qb == 2)
+      prefill_attn_dma_kernel<2><<<gridd, 256, 3 * PA_STAGE_B, st>>>(q_rot, (long)Hq * 128, 128, k_rot, v_lin, (long)L * 128, (bf16_t*)out, o_stride, 128,
+                                                                   T, L, L - T, Hq, Hkv, scale, ns, part_o, part_ml);
+    else
+      prefill_attn_dma_kernel<1><<<gridd, 256, 3 * PA_STAGE_B, st>>>(q_rot, (long)Hq * 128, 128, k_rot, v_lin, (long)L * 128, (bf16_t*)out, o_stride, 128,
+                                                                   T, L, L - T, Hq, Hkv, scale, ns, part_o, part_ml);
+    rc = svlm_check_launch("svlm_prefill_attn_ropeload");
+    if (rc || ns == 1) return rc;
+    const long n_thrd = (long)T * Hq * 32;
+    flash_combine_kernel<<<(int)((n_thrd + 255) / 256), 256, 0, st>>>(part_o, part_ml, (bf16_t*)out, o_stride, T, Hq, ns, scale);
+    return svlm_check_launch("svlm_prefill_attn_ropeload(combine)");
+  }
+  if (qb == 2 && ng != 2) {
+    dim3 grid2((T + 127) / 128, Hq, ns);
+    fa_prepare<128, 128, 1, 2>();
+    flash_attn_kernel<128, 128, 1, 2><<<grid2, 256, fa_smem_bytes<128, 128, 1>(), st>>>(
+        q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out, o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv,
+        scale, ns, part_o, part_ml);
+    rc = svlm_check_launch("svlm_prefill_attn_ropeload");
+    if (rc || ns == 1) return rc;
+    const long n_thr2 = (long)T * Hq * 32;
+    flash_combine_kernel<<<(int)((n_thr2 + 255) / 256), 256, 0, st>>>(part_o, part_ml, (bf16_t*)out, o_stride, T, Hq, ns, scale);
+    return svlm_check_launch("svlm_prefill_attn_ropeload(combine)");
+  }
+  dim3 grid((T + 63) / 64, Hq, ns);
   if (ng == 2) {
     fa_prepare<128, 128, 2>();
     flash_attn_kernel<128, 128, 2><<<grid, 512, fa_smem_bytes<128, 128, 2>(), st>>>(
@@ -494,6 +795,7 @@ extern "C" int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len,
   SVLM_CHECK_ARG(d == 80 || d == 128, "svlm_vit_attn: head_dim %d unsupported (80 or 128)", d);
   SVLM_CHECK_ARG(n_seq >= 0 && seq_len > 0 && H > 0, "svlm_vit_attn: bad shape n_seq=%d seq_len=%d H=%d", n_seq, seq_len, H);
   if (n_seq == 0) return SVLM_OK;
+  SVLM_CHECK_ARG((long long)(seq_len + 256) * 3 * H * d * 2 < (1LL << 31), "svlm_vit_attn: seq_len=%d exceeds the 32-bit buffer offsets of the attention kernel", seq_len);
   const bf16_t* base = (const bf16_t*)qkv;
   const long row = 3L * H * d;
   dim3 grid((seq_len + 63) / 64, H, n_seq);

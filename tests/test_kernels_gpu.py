@@ -316,7 +316,9 @@ def test_decode_attn(ops, ref, Hq, Hkv, L, chunk):
 # (2,1,700,700) and (4,2,300,1000) run 5 / 7 key splits whose last ones start beyond some queries' causal limit (rows that
 # are fully masked inside a split); (12,2,275,2330) is the steady-state chunk of BASELINE configs[1] (4 splits)
 @pytest.mark.parametrize("Hq,Hkv,T,L", [(12, 2, 275, 2330), (28, 4, 40, 300), (4, 2, 1, 1), (4, 2, 20, 20), (4, 2, 37, 100), (6, 1, 16, 48),
-                                        (2, 1, 700, 700), (4, 2, 300, 1000), (2, 2, 130, 257)])
+                                        (2, 1, 700, 700), (4, 2, 300, 1000), (2, 2, 130, 257),
+                                        # T >= 1024 without key splits: two query blocks per wave (the dense prefill's 4096-row passes)
+                                        (4, 2, 1100, 1500), (7, 1, 1024, 1024), (2, 1, 1090, 3001)])
 def test_prefill_attn(ops, ref, Hq, Hkv, T, L):
     cap = ((L + 63) // 64) * 64
     pool, slot_of, rope = _attn_setup(Hq, Hkv, L, cap, 20)
