@@ -626,6 +626,9 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       }
     }
   }
+  // large-M, long-K GEMMs (the dense prefill's 4096-row passes on the 7B shapes): 128-row tiles on the 2-stage ring, two workgroups
+  // per CU -- 610-740 -> 710-820 TFLOP/s against the 64-row tiles (tools/gemm_big.py); K = 1280 (the ViT's batches) gains nothing
+  if (M >= 2048 && K >= 2048 && best_splits == 1 && getenv("SVLM_GEMM_NO_T128") == nullptr) best_bm = 128;
   if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
     const int fb = atoi(force);
     best_bm = (fb == 192 || fb == 320) ? fb : (fb == 128 && M > 64 ? 128 : 64);
@@ -679,6 +682,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       }
       dma_attr_done = true;
     }
+    const bool tall_unsplit_ns2 = M >= 2048 || getenv("SVLM_GEMM_T128NS2") != nullptr;
     if (bm == 192 || bm == 320) {
       // tall tiles for skinny-M weight-streaming GEMMs (prefill: M ~ 290): 2 x 192 rows, or ALL rows in one 320-row tile so that
       // W is streamed exactly once; 320 rows leave LDS for a 2-stage ring only
@@ -714,6 +718,21 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
         ns2_done = true;
       }
       gemm_glds_kernel<2, 2><<<grid, 256, DLDS2S, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                               (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+    } else if (!small && splits == 1 && tall_unsplit_ns2) {
+      // un-split 128-row tiles on a 2-stage ring: 64 KB of LDS, TWO workgroups per CU (large-M GEMMs: the dense prefill's 4096-row
+      // passes, the ViT's 8-grid batches)
+      constexpr int DLDS4S = 2 * (128 + GEMM_BN) * 128;
+      static bool ns2t_done = false;
+      if (!ns2t_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS4S);
+        if (e1 != hipSuccess) {
+          svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", DLDS4S, hipGetErrorString(e1));
+          return SVLM_ELAUNCH;
+        }
+        ns2t_done = true;
+      }
+      gemm_glds_kernel<4, 2><<<grid, 256, DLDS4S, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
     } else if (small) {
       gemm_glds_kernel<2, NS2><<<grid, 256, DLDS2, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,

@@ -68,6 +68,9 @@ def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
     (290, 4608, 3584, True, False, 0),      # 7B qkv (BM 64, 2 splits)
     (1024, 1280, 3424, True, True, 0),      # Qwen2.5 ViT down_proj (padded intermediate size)
     (256, 3584, 5120, True, False, 0),      # merger mlp.2 -> 7B
+    # large M, long K: 128-row tiles on the 2-stage ring (the dense prefill's LLM passes), ragged in M and N
+    (2100, 392, 2048, True, True, 0),
+    (2048, 256, 2112, False, False, 1),
 ])
 def test_gemm(ops, ref, M, N, K, bias, res, act):
     A, W = rnd((M, K), 1), rnd((N, K), 2, 0.05)
@@ -109,7 +112,7 @@ def test_gemm_norm_fused_reduce(ops, ref, M, N, K):
     assert float(d.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64)])
+@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64), (2050, 192, 2048)])
 def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
     """ACT_SWIGLU: W = [gate rows; up rows]; every tile pairs 64 gate with the 64 matching up columns and applies
     bf16(bf16(silu(g)) * u) in its epilogue == GEMM to (M, 2I) followed by svlm_silu_mul, for both tile heights."""
@@ -125,7 +128,8 @@ def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
         got = ops.gemm(A.cuda(), W.cuda(), act=4)
         assert got.shape == (M, I)
         close(f"gemm swiglu bm={bm}", got, want)
-        assert torch.equal(got, sep) or bm is not None, "default plan: same K order as the separate launches -> same bits"
+        # (the large-M case's separate (M, 2I) GEMM has too few tiles and splits K: another summation order)
+        assert torch.equal(got, sep) or bm is not None or M >= 2048, "default plan: same K order as the separate launches -> same bits"
     # with the [gate; up] bias of the Qwen2.5 vision MLP
     b = rnd((2 * I,), 3, 0.2)
     close("gemm swiglu + bias", ops.gemm(A.cuda(), W.cuda(), bias=b.cuda(), act=4), ref.gemm(A, W, bias=b, act=4))
