@@ -196,16 +196,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #ifndef GEMM_DIAG
 #define GEMM_DIAG 0
 #endif
-template <int TM, int NS>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict__ A, int lda,
+template <int TM, int NS, int WM = 2>
+__global__ __launch_bounds__(128 * WM) void gemm_glds_kernel(const bf16_t* __restrict__ A, int lda,
                                                         const bf16_t* __restrict__ W, int ldw,
                                                         const bf16_t* __restrict__ bias,
                                                         const bf16_t* residual, int ldr,
                                                         bf16_t* C, int ldc, float* __restrict__ partial,
                                                         int M, int N, int K, int k_per_split, int act, int gm, int gn, int splits) {
-  constexpr int BM = 32 * TM;
-  constexpr int A_INST = BM / 32;               // 1-KiB DMA pieces (8 rows x 128 B) per wave per tile: A
-  constexpr int W_INST = GEMM_BN / 32;          // ... and W
+  // 2 WM waves as WM (m) x 2 (n), TM x 4 MFMA tiles each: WM = 2 is the 4-wave workgroup of the (32 TM) x 128 tiles; WM = 4 an
+  // 8-wave workgroup on a 256 x 128 tile (TM = 4): 85 flop per staged byte against 64 / 44 for the 128- / 64-row tiles, two
+  // waves per SIMD from ONE workgroup per CU
+  constexpr int BM = 16 * TM * WM;
+  constexpr int A_INST = TM;                    // 1-KiB DMA pieces (8 rows x 128 B) per wave per tile: A (BM / 8 pieces over 2 WM waves)
+  constexpr int W_INST = 8 / WM;                // ... and W (16 pieces)
 #if GEMM_DIAG == 3                               // DMA-only loop that streams W alone: is the DMA stream bound per byte or per step?
   constexpr int NPT = W_INST;
 #else
@@ -628,16 +631,22 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   }
   // large-M, long-K GEMMs (the dense prefill's 4096-row passes on the 7B shapes): 128-row tiles on the 2-stage ring, two workgroups
   // per CU -- 610-740 -> 710-820 TFLOP/s against the 64-row tiles (tools/gemm_big.py); K = 1280 (the ViT's batches) gains nothing
-  if (M >= 2048 && K >= 2048 && best_splits == 1 && getenv("SVLM_GEMM_NO_T128") == nullptr) best_bm = 128;
+  // and 256 x 128 tiles (8 waves, one workgroup per CU) where their grid fills whole rounds of the 256 CUs: 7B down_proj 821 -> 927,
+  // gate/up 820 -> 886 TFLOP/s; 7B qkv (576 tiles = 2.25 rounds) stays on the 128-row tiles
+  if (M >= 2048 && K >= 2048 && best_splits == 1 && getenv("SVLM_GEMM_NO_T128") == nullptr) {
+    const long long t256 = (long long)((M + 255) / 256) * gn;
+    const long long rounds = (t256 + 255) / 256;
+    best_bm = (t256 * 100 >= rounds * 256 * 85) ? 256 : 128;
+  }
   if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
     const int fb = atoi(force);
-    best_bm = (fb == 192 || fb == 320) ? fb : (fb == 128 && M > 64 ? 128 : 64);
+    best_bm = (fb == 192 || fb == 320 || fb == 256) ? fb : (fb == 128 && M > 64 ? 128 : 64);
     if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
     if ((long long)best_splits * M * N * 4 > ws_bytes || ws == nullptr || K < 1024) best_splits = 1;
   }
   if (swiglu) {                       // one K pass (the pairing happens in the epilogue), register budget of the 64/128-row tiles
     best_splits = 1;
-    if (best_bm > 128) best_bm = 128;
+    if (best_bm > 128 && best_bm != 256) best_bm = 128;
   }
   const bool small = best_bm == 64;
   const int bm = best_bm;
@@ -664,7 +673,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
     attr_done = true;
   }
   const bool dma = (K % GEMM_BK == 0) && getenv("SVLM_GEMM_NO_DMA") == nullptr;
-  if (!dma && (bm == 192 || bm == 320 || swiglu)) {
+  if (!dma && (bm == 192 || bm == 320 || bm == 256 || swiglu)) {
     svlm_set_error("svlm_gemm_bf16: tall tiles and SVLM_ACT_SWIGLU run on the LDS-DMA kernel only (K %% 64 == 0, SVLM_GEMM_NO_DMA unset)");
     return SVLM_EINVAL;
   }
@@ -683,7 +692,20 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       dma_attr_done = true;
     }
     const bool tall_unsplit_ns2 = M >= 2048 || getenv("SVLM_GEMM_T128NS2") != nullptr;
-    if (bm == 192 || bm == 320) {
+    if (bm == 256) {
+      constexpr int NS8 = 3, DLDS8 = NS8 * (256 + GEMM_BN) * 128;
+      static bool w8_done = false;
+      if (!w8_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<4, NS8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DLDS8);
+        if (e1 != hipSuccess) {
+          svlm_set_error("svlm_gemm_bf16: cannot reserve %d B of LDS: %s", DLDS8, hipGetErrorString(e1));
+          return SVLM_ELAUNCH;
+        }
+        w8_done = true;
+      }
+      gemm_glds_kernel<4, NS8, 4><<<grid, 512, DLDS8, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                                                    (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
+    } else if (bm == 192 || bm == 320) {
       // tall tiles for skinny-M weight-streaming GEMMs (prefill: M ~ 290): 2 x 192 rows, or ALL rows in one 320-row tile so that
       // W is streamed exactly once; 320 rows leave LDS for a 2-stage ring only
       constexpr int DLDS6 = 3 * (192 + GEMM_BN) * 128, DLDS10 = 2 * (320 + GEMM_BN) * 128;

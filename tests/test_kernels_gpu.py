@@ -81,7 +81,7 @@ def test_gemm(ops, ref, M, N, K, bias, res, act):
     close(f"gemm {M}x{N}x{K} act{act}", got, want)
 
 
-@pytest.mark.parametrize("bm,splits", [(64, 1), (64, 5), (128, 1), (128, 3), (128, 8), (192, 1), (192, 4), (320, 1), (320, 8)])
+@pytest.mark.parametrize("bm,splits", [(64, 1), (64, 5), (128, 1), (128, 3), (128, 8), (192, 1), (192, 4), (320, 1), (320, 8), (256, 1), (256, 4)])
 def test_gemm_every_plan_is_numerically_the_same_op(ops, ref, bm, splits, monkeypatch):
     """Tile height and split-K are performance choices only: forced through the tuning switches, each plan must pass the
     same bar as the default one."""
