@@ -422,10 +422,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 2
   }
   const int qbase_s = __builtin_amdgcn_readfirstlane(qbase);
 
-  // The tile's tail comes in two variants picked by a scalar branch once the scores are known: RESCALE = false when no query of
-  // the wave saw a new maximum (nearly every tile after the first few: no alpha, no pass over the accumulators), RESCALE = true
-  // multiplies unconditionally.  (A conditional rescale INSIDE one body makes hipcc merge the accumulator tuples of both paths
-  // through copies: 256 VGPRs plus scratch at two query blocks per wave, against 165 for either variant alone.)
+  // Online softmax with a LAZY reference: p = exp2(s*c - m_ref) is exact for ANY reference that keeps it in range, so the running
+  // maximum is not tracked tile by tile.  The fast tail costs one FMA, one bare v_exp_f32, one add and half a convert per score --
+  // no max tree, no cross-lane exchange, no pass over the accumulators -- and only checks that no lane's partial row sum left the
+  // safe range (a score more than ~12 binades above the reference, or the very first tile, whose reference is -1e30: exp2 gives
+  // +inf and the test fires before p is used).  The slow tail then takes the exact maximum as the new reference and rescales.
+  // The two tails are whole variants picked by a scalar branch (a conditional rescale inside one body makes hipcc merge the
+  // accumulator tuples of both paths through copies: 256 VGPRs plus scratch at two query blocks per wave, against 165).
+  constexpr float LAZY_SUM_MAX = 4096.f;
   auto compute_t = [&](int kt, auto stage_c, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     constexpr int SB = decltype(stage_c)::value * PA_STAGE_B;
@@ -443,60 +447,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 2
         for (int qb = 0; qb < QB; ++qb) sacc[qb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qb][ks], sacc[qb][sub], 0, 0, 0);
       }
     }
-    float sv[QB][8], m_new[QB];
-    unsigned okbits[QB];
-    bool grew = false;
+    // per query block: fast attempt, exact redo when the reference has to move (only scalars-per-lane change inside that branch);
+    // the accumulators are touched by whole variants of the P.V stage only
+    bf16x8_t pb[QB];
+    float alpha[QB];
+    bool moved = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      const int tq = qbase + qb * 16 + fr;
+      float p[8], rs = 0.f;
+      bool big = MASK;
+      if constexpr (!MASK) {
+        const float mref = -m_run[qb];
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[qb][sub * 4 + r] = sacc[qb][sub][r] * cexp;
-      okbits[qb] = 0xFFu;
-      if constexpr (MASK) {
-        okbits[qb] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int j = j0 + (i >> 2) * 16 + fq * 4 + (i & 3);
-          const bool ok = j < L && j <= tq + causal_offset;
-          sv[qb][i] = ok ? sv[qb][i] : -1e30f;
-          okbits[qb] |= ok ? (1u << i) : 0u;
-        }
+          for (int r = 0; r < 4; ++r) {
+            p[sub * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sacc[qb][sub][r], cexp, mref));
+            rs += p[sub * 4 + r];
+          }
+        big = __any(!(rs <= LAZY_SUM_MAX));
       }
-      float mx = fmaxf(fmaxf(fmaxf(sv[qb][0], sv[qb][1]), fmaxf(sv[qb][2], sv[qb][3])),
-                       fmaxf(fmaxf(sv[qb][4], sv[qb][5]), fmaxf(sv[qb][6], sv[qb][7])));
-      mx = xor32_max(xor16_max(mx));
-      m_new[qb] = fmaxf(m_run[qb], mx);
-      grew = grew || m_new[qb] > m_run[qb];
-    }
-    auto finish = [&](auto rescale_tag) {
-      constexpr bool RESCALE = decltype(rescale_tag)::value;
-      bf16x8_t pb[QB];
+      alpha[qb] = 1.f;
+      if (big) {                   // exact maximum, new reference
+        const int tq = qbase + qb * 16 + fr;
+        float sv[8];
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        float p[8], rs = 0.f;
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sv[qb][i] - m_new[qb]);     // masked scores (-1e30) underflow to 0 ...
+          for (int r = 0; r < 4; ++r) sv[sub * 4 + r] = sacc[qb][sub][r] * cexp;
+        unsigned okbits = 0xFFu;
+        if constexpr (MASK) {
+          okbits = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int j = j0 + (i >> 2) * 16 + fq * 4 + (i & 3);
+            const bool ok = j < L && j <= tq + causal_offset;
+            sv[i] = ok ? sv[i] : -1e30f;
+            okbits |= ok ? (1u << i) : 0u;
+          }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        mx = xor32_max(xor16_max(mx));
+        const float m_new = fmaxf(m_run[qb], mx);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sv[i] - m_new);     // masked scores (-1e30) underflow to 0 ...
         if constexpr (MASK) {                                // ... unless the whole row is masked so far (m still -1e30)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) p[i] = (okbits[qb] >> i) & 1u ? p[i] : 0.f;
+          for (int i = 0; i < 8; ++i) p[i] = (okbits >> i) & 1u ? p[i] : 0.f;
         }
+        rs = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) rs += p[i];
-        if constexpr (RESCALE) {
-          const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new[qb]);
+        alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        m_run[qb] = m_new;
+        moved = true;
+      }
+      l_run[qb] = l_run[qb] * alpha[qb] + rs;               // this lane's 8 keys of every tile; summed over the query's 4 lanes at the end
+      u32x4_t pk = pack8(p);
+      pb[qb] = *reinterpret_cast<bf16x8_t*>(&pk);
+    }
+    auto pv = [&](auto rescale_tag) {
+      if constexpr (decltype(rescale_tag)::value) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
           for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) oacc[qb][dt][r] *= alpha;
-          l_run[qb] = l_run[qb] * alpha + rs;               // this lane's 8 keys of every tile; summed over the query's 4 lanes at the end
-          m_run[qb] = m_new[qb];
-        } else {
-          l_run[qb] += rs;
-        }
-        u32x4_t pk = pack8(p);
-        pb[qb] = *reinterpret_cast<bf16x8_t*>(&pk);
+            for (int r = 0; r < 4; ++r) oacc[qb][dt][r] *= alpha[qb];
       }
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
@@ -507,12 +524,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB == 2 ? 2
         for (int qb = 0; qb < QB; ++qb) oacc[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[qb], oacc[qb][dt], 0, 0, 0);
       }
     };
-    if constexpr (MASK) {
-      finish(std::true_type{});
-    } else {
-      if (__any(grew)) finish(std::true_type{});
-      else finish(std::false_type{});
-    }
+    if (moved) pv(std::true_type{});
+    else pv(std::false_type{});
   };
   auto step = [&](int kt, auto stage_c) {
     constexpr int S = decltype(stage_c)::value;

@@ -334,6 +334,31 @@ def test_prefill_attn(ops, ref, Hq, Hkv, T, L):
     close(f"prefill_attn Hq{Hq} Hkv{Hkv} T{T} L{L}", out, want, max_tol=2 ** -6, mean_tol=1e-3)
 
 
+@pytest.mark.parametrize("T,L,step", [(1100, 1500, False), (200, 900, False), (64, 64, False), (1100, 1500, True), (300, 640, True)])
+def test_prefill_attn_reference_moves_along_the_sequence(ops, ref, T, L, step):
+    """The prefill kernel keeps a LAZY softmax reference (exact maximum only when a lane's partial row sum leaves the safe range).
+    Keys whose scores climb by ~160 binades along the sequence (or jump by ~300 at once) force the reference to move again and again, the first jumps past
+    the range of exp2 itself (+inf in the fast path, which must be caught before it is used)."""
+    Hq, Hkv = 2, 1
+    cap = ((L + 63) // 64) * 64
+    pool, slot_of, _ = _attn_setup(Hq, Hkv, L, cap, 33)
+    rope = torch.zeros((cap, 128), dtype=BF16)
+    rope[:, :64] = 1.0                                      # cos = 1, sin = 0: no rotation
+    u = torch.full((128,), 0.5)
+    ramp = torch.arange(L, dtype=torch.float32) * (40.0 / L)
+    if step:                                                # ... or jump by ~300 binades in the middle of a tile, half way through
+        ramp = torch.where(torch.arange(L) < L - T // 2 - 5, torch.zeros(L), torch.full((L,), 75.0))
+    k_rows = (u[None, :] * ramp[:, None]).to(BF16)          # q.k * scale * log2(e) runs from 0 to ~163
+    pool[0, 0, 0, slot_of[:L].long()] = k_rows
+    q = (u.repeat(Hq)[None, :] + rnd((T, Hq * 128), 7, 0.01).float()).to(BF16).contiguous()
+    scale = 1 / math.sqrt(128)
+    want = ref.prefill_attn(q, pool, 0, slot_of, rope, torch.empty((T, Hq * 128), dtype=BF16), T, L, Hq, scale)
+    out = torch.empty((T, Hq * 128), dtype=BF16, device="cuda")
+    ops.prefill_attn(q.cuda(), pool.cuda(), 0, slot_of.cuda(), rope.cuda(), out, T, L, Hq, scale)
+    assert torch.isfinite(out.float()).all()
+    close(f"prefill_attn climbing scores T{T} L{L}", out, want, max_tol=2 ** -6, mean_tol=1e-3)
+
+
 def test_prefill_attn_appends_the_new_rows(ops, ref):
     """k_new / v_new handed to the prefill attention are written to their pool slots (== svlm_kv_append) by the launch that
     rotates the keys, and the result equals append-then-attend."""
