@@ -312,7 +312,7 @@ def roofline_pass(model, args, kv_len):
     c2.reserve(Lp)
     c2.commit(Lp)
     c2.sync_device()
-    timed("rope_gather_kernel+flash_attn_kernel<128,128>(prefill)", NL, NL, 2 * Lp * Hkv * D * 2 * 2 + 2 * T * Hq * D * 2,
+    timed("rope_gather_kernel+prefill_attn_dma_kernel+flash_combine_kernel(prefill)", NL, NL, 2 * Lp * Hkv * D * 2 * 2 + 2 * T * Hq * D * 2,
           4.0 * T * (Lp - T / 2.0) * Hq * D,
           lambda: [o.prefill_attn(qkv[:, :qd], c2.pool, i, c2.slot_of_dev, eng.rope_cs, att, T, Lp, Hq, scale) for i in range(NL)])
     N = (args.size // 14) ** 2
