@@ -68,6 +68,8 @@ def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
     (290, 4608, 3584, True, False, 0),      # 7B qkv (BM 64, 2 splits)
     (1024, 1280, 3424, True, True, 0),      # Qwen2.5 ViT down_proj (padded intermediate size)
     (256, 3584, 5120, True, False, 0),      # merger mlp.2 -> 7B
+    (1024, 3840, 1280, True, False, 0),     # ViT qkv: 128-row tiles on 8 waves, one workgroup per CU
+    (1000, 3840, 1280, True, False, 0),     # ... ragged in M
     # large M, long K: 128-row tiles on the 2-stage ring (the dense prefill's LLM passes), ragged in M and N
     (2100, 392, 2048, True, True, 0),
     (2048, 256, 2112, False, False, 1),
