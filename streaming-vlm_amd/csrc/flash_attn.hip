@@ -7,13 +7,18 @@
 // Numerics follow flash-attn: fp32 scores and online softmax, P rounded to bf16 before P.V,
 // fp32 accumulation, one final division and rounding.
 //
-// Prefill runs in two launches per layer: `rope_gather_kernel` applies the shrink-mode post-cache
+// Prefill runs in two launches per layer (three with key splits): `rope_gather_kernel` applies the shrink-mode post-cache
 // M-RoPE (bf16 x*cos + rotate_half(x)*sin, qwen2/language_forward.py:9-64) ONCE to every cached key
 // while gathering K and V from their slots into logical order, and rotates the T query rows; the
 // attention kernel then streams dense tiles.  (The reference rotates all keys in every layer too,
 // and additionally materialises repeat_kv.)
 //
-// Attention kernel: a workgroup = 4 waves x 16 queries of one head.  Both products put the LDS-staged
+// Two attention kernels share the products and the numerics:
+//   flash_attn_kernel        (ViT, d = 80 or 128; and the prefill behind SVLM_PREFILL_NO_DMA) -- K / V through buffer descriptors
+//                            into a two-slot register ring and padded LDS rows, online softmax with the exact running maximum
+//   prefill_attn_dma_kernel  (LLM prefill, d = 128) -- K / V by LDS-DMA into XOR-swizzled unpadded rows, one or two query blocks per
+//                            wave, lazy softmax reference, one or two tiles per barrier (further down)
+// A workgroup = 4 waves x 16 (x QB) queries of one head.  Both products put the LDS-staged
 // operand in the MFMA "A" slot and keep the other in registers:
 //   S^T[key][q] = K[key][:] . Q[q][:]      (A = K rows from LDS,   B = Q fragment, loop-invariant)
 //   O^T[d][q]   = V^T[d][key] . P^T[key][q] (A = V^T via ds_read_b64_tr_b16 of row-major V in LDS, B = P, straight from the S^T
@@ -21,8 +26,6 @@
 //                                            so softmax stats, P and O never leave the lane)
 // The k-slot <-> key mapping of the second product is the permutation that makes the S^T
 // accumulator registers a valid B fragment; V^T is read with the same permutation.
-// Pipeline: two LDS stages + a two-slot register ring; the global loads of key tile t+3 are issued while tile t is
-// computed (two iterations to land), one barrier per 32-key tile.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -799,18 +802,6 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
     if (rc || ns == 1) return rc;
     const long n_thrd = (long)T * Hq * 32;
     flash_combine_kernel<<<(int)((n_thrd + 255) / 256), 256, 0, st>>>(part_o, part_ml, (bf16_t*)out, o_stride, T, Hq, ns, scale);
-    return svlm_check_launch("svlm_prefill_attn_ropeload(combine)");
-  }
-  if (qb == 2 && ng != 2) {
-    dim3 grid2((T + 127) / 128, Hq, ns);
-    fa_prepare<128, 128, 1, 2>();
-    flash_attn_kernel<128, 128, 1, 2><<<grid2, 256, fa_smem_bytes<128, 128, 1>(), st>>>(
-        q_rot, (long)Hq * 128, 128, 0, k_rot, v_lin, 128, (long)L * 128, 0, (bf16_t*)out, o_stride, 128, 0, T, L, L - T, 1, Hq, Hkv,
-        scale, ns, part_o, part_ml);
-    rc = svlm_check_launch("svlm_prefill_attn_ropeload");
-    if (rc || ns == 1) return rc;
-    const long n_thr2 = (long)T * Hq * 32;
-    flash_combine_kernel<<<(int)((n_thr2 + 255) / 256), 256, 0, st>>>(part_o, part_ml, (bf16_t*)out, o_stride, T, Hq, ns, scale);
     return svlm_check_launch("svlm_prefill_attn_ropeload(combine)");
   }
   dim3 grid((T + 63) / 64, Hq, ns);
