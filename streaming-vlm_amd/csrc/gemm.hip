@@ -601,12 +601,14 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   // ---- tuned plans: shapes of the supported models measured on MI355X (tools/gemm_tune_table.py, cold weights).  The cost
   // model above mis-ranks some of them (it knows nothing of co-resident workgroups sharing a CU's LDS-DMA stream); an entry
   // applies to its exact (N, K) and row bucket ceil(M/64) +- 1.
-  struct GemmPlan { int mb, N, K, bm, splits, w8; };      // w8: the 128-row tile on 8 waves, one workgroup per CU
+  struct GemmPlan { int mb, N, K, bm, splits, variant; }; // variant of the 128-row tile: 1 = 8 waves (one workgroup per CU), 2 = 2-stage ring (two per CU)
   static const GemmPlan kTunedPlans[] = {
       {5, 1536, 8960, 64, 4},      // Qwen2-VL-2B down_proj, prefill: 24.6 us vs 28.3 us for the cost model's choice
       {5, 4608, 3584, 64, 2},      // 7B qkv: 26.5 vs 29.9
       {5, 3584, 3584, 64, 3},      // 7B o_proj: 22.9 vs 27.8
       {5, 3584, 18944, 320, 8},    // 7B down_proj: 66.2 (all rows in one 320-row tile) vs 123.6
+      {10, 3584, 18944, 128, 3},   // 7B down_proj at two temporal grids per chunk (M ~ 590: 4 frames per second): 145 vs 248 us
+      {10, 18944, 3584, 128, 1, 2},// 7B gate/up (SwiGLU pairing) at M ~ 590: 206 vs 253 us on the 64-row tiles
       {5, 2560, 2048, 64, 3},      // Qwen2.5-VL-3B qkv: 16.3 vs 18.1
       {5, 2048, 2048, 64, 3},      // 3B o_proj: 14.4 vs 15.6
       {5, 2048, 11008, 64, 4},     // 3B down_proj: 33.3 vs 43.2
@@ -620,14 +622,15 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       {4, 3584, 5120, 128, 4},     // merger mlp.2 -> 7B: 25.1 vs 36.1
       {4, 2048, 5120, 64, 4},      // merger mlp.2 -> 3B: 19.7 vs 21.5
   };
-  bool plan_w8 = false;
+  bool plan_w8 = false, plan_ns2 = false;
   if (getenv("SVLM_GEMM_NO_TABLE") == nullptr) {
     const int mb = (M + 63) / 64;
     for (const GemmPlan& p : kTunedPlans) {
       if (p.N == N && p.K == K && mb >= p.mb - 1 && mb <= p.mb + 1 && (p.splits == 1 || (ws != nullptr && (long long)p.splits * M * N * 4 <= ws_bytes))) {
         best_bm = p.bm;
         best_splits = p.splits;
-        plan_w8 = p.w8 != 0;
+        plan_w8 = p.variant == 1;
+        plan_ns2 = p.variant == 2;
         break;
       }
     }
@@ -644,7 +647,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
     const int fb = atoi(force);
     best_bm = (fb == 192 || fb == 320 || fb == 256) ? fb : (fb == 128 && M > 64 ? 128 : 64);
-    plan_w8 = false;
+    plan_w8 = plan_ns2 = false;
     if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
     if ((long long)best_splits * M * N * 4 > ws_bytes || ws == nullptr || K < 1024) best_splits = 1;
   }
@@ -695,7 +698,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       }
       dma_attr_done = true;
     }
-    const bool tall_unsplit_ns2 = M >= 2048 || getenv("SVLM_GEMM_T128NS2") != nullptr;
+    const bool tall_unsplit_ns2 = M >= 2048 || plan_ns2 || getenv("SVLM_GEMM_T128NS2") != nullptr;
     static const bool w8_128 = getenv("SVLM_GEMM_W8") != nullptr;       // tuning aid: force the 8-wave 128 x 128 tile
     if (bm == 128 && splits == 1 && !swiglu && (w8_128 || plan_w8)) {
       constexpr int DL = 3 * (128 + GEMM_BN) * 128;

@@ -66,6 +66,7 @@ def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
     # shapes that take their (tile rows, split-K) from the tuned-plan table rather than from the cost model
     (290, 3584, 18944, False, True, 0),     # 7B down_proj (BM 128, 3 splits)
     (290, 4608, 3584, True, False, 0),      # 7B qkv (BM 64, 2 splits)
+    (590, 3584, 18944, False, True, 0),     # 7B down_proj at two temporal grids per chunk (BM 128, 3 splits)
     (1024, 1280, 3424, True, True, 0),      # Qwen2.5 ViT down_proj (padded intermediate size)
     (256, 3584, 5120, True, False, 0),      # merger mlp.2 -> 7B
     (1024, 3840, 1280, True, False, 0),     # ViT qkv: 128-row tiles on 8 waves, one workgroup per CU
@@ -114,7 +115,7 @@ def test_gemm_norm_fused_reduce(ops, ref, M, N, K):
     assert float(d.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64), (2050, 192, 2048)])
+@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (590, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64), (2050, 192, 2048)])
 def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
     """ACT_SWIGLU: W = [gate rows; up rows]; every tile pairs 64 gate with the 64 matching up columns and applies
     bf16(bf16(silu(g)) * u) in its epilogue == GEMM to (M, 2I) followed by svlm_silu_mul, for both tile heights."""

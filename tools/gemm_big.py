@@ -10,14 +10,15 @@ from streaming_vlm_amd._lib import ACT_NONE, ACT_SWIGLU
 o = HipOps()
 bf = torch.bfloat16
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.05).to(bf)
-shapes = [("7b qkv", 4096, 4608, 3584, ACT_NONE), ("7b o", 4096, 3584, 3584, ACT_NONE), ("7b gate_up", 4096, 18944, 3584, ACT_SWIGLU),
-          ("7b down", 4096, 3584, 18944, ACT_NONE), ("vit qkv", 8192, 3840, 1280, ACT_NONE), ("vit proj", 8192, 1280, 1280, ACT_NONE),
+M7 = int(os.environ.get("GB_M", 4096))       # rows of the 7B shapes (590 = the streaming chunk of configs[2])
+shapes = [("7b qkv", M7, 4608, 3584, ACT_NONE), ("7b o", M7, 3584, 3584, ACT_NONE), ("7b gate_up", M7, 18944, 3584, ACT_SWIGLU),
+          ("7b down", M7, 3584, 18944, ACT_NONE), ("vit qkv", 8192, 3840, 1280, ACT_NONE), ("vit proj", 8192, 1280, 1280, ACT_NONE),
           ("vit fc1", 8192, 5120, 1280, ACT_NONE), ("vit fc2", 8192, 1280, 5120, ACT_NONE)]
 only = sys.argv[1] if len(sys.argv) > 1 else None
 for name, M, N, K, act in shapes:
     if only and only not in name:
         continue
-    nW = 4
+    nW = 4 if M >= 2048 else 12
     Ws = [r(2 * N if act == ACT_SWIGLU else N, K) for _ in range(nW)]
     A, C = r(M, K), torch.empty(M, N, dtype=bf, device="cuda")
     fn = lambda: [o.gemm(A, W, out=C, act=act) for W in Ws]
