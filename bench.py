@@ -205,6 +205,8 @@ def main():
     if rank == 0 and not args.no_roofline:
         log("roofline pass (eager launches bracketed by HIP events)")
         out.update(roofline_pass(model, args, kv_steady[0]))
+    if rank == 0 and dense:
+        out.update(dense_prefill_rooflines(model, out["dense_prefill"]["prompt_rows"]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dense:
         log("cpu baseline (oracle on host cores)")
         out["cpu_baseline"] = cpu_baseline(cfg, sd, args)
@@ -213,6 +215,59 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def dense_prefill_rooflines(model, prompt_rows):
+    """configs[4]: the two MFMA kernels that carry the opening forward, timed live at its LAST pass (PREFILL_ROWS query rows over
+    the whole prompt): causal attention of one layer and the four projection GEMMs of one layer, HIP events on the launching stream."""
+    import math
+    eng = model._svlm_engine
+    o, w, tc = eng.ops, eng.w, eng.cfg.text
+    dev = eng.device
+    H, I, D, Hq, Hkv, qd, kd = tc.hidden_size, tc.intermediate_size, tc.head_dim, tc.num_heads, tc.num_kv_heads, eng.qd, eng.kd
+    T = min(eng.PREFILL_ROWS, prompt_rows)
+    L = min(prompt_rows, eng.max_len)
+    c = eng.new_cache()
+    c.reserve(L)
+    c.commit(L)
+    c.sync_device()
+    c.pool[0].normal_()                  # random K / V rows: zero-filled operands read high (lower toggle rate, higher clock)
+    bf = torch.bfloat16
+    q = torch.randn((T, qd), device=dev).to(bf)
+    att = torch.empty((T, qd), dtype=bf, device=dev)
+    x = torch.randn((T, H), device=dev).to(bf)
+    qkv = torch.empty((T, qd + 2 * kd), dtype=bf, device=dev)
+    hm = torch.empty((T, I), dtype=bf, device=dev)
+    l0 = w.layers[0]
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            best = s.elapsed_time(e) if best is None else min(best, s.elapsed_time(e))
+        return best
+    ms_a = timed(lambda: o.prefill_attn(q, c.pool, 0, c.slot_of_dev, eng.rope_cs, att, T, L, Hq, 1.0 / math.sqrt(D)))
+    fl_a = 4.0 * T * (L - T / 2.0) * Hq * D
+
+    def gemms():
+        o.gemm(x, l0["qkv_w"], bias=l0["qkv_b"], out=qkv)
+        o.gemm(att, l0["o_w"], residual=x, out=x)
+        o.gemm(x, l0["gu_w"], out=hm, act=eng_act_swiglu)
+        o.gemm(hm, l0["down_w"], residual=x, out=x)
+    from streaming_vlm_amd._lib import ACT_SWIGLU as eng_act_swiglu
+    ms_g = timed(gemms)
+    fl_g = 2.0 * T * H * ((qd + 2 * kd) + qd + 2 * I + I)
+    mk = lambda kern, ms, fl, extra: dict({"kernel": kern, "bound": "mfma", "achieved": round(fl / ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                           "frac": round(fl / ms / 1e9 / 2500.0, 4), "avg_launch_us": round(ms * 1e3, 1), "traffic": None}, **extra)
+    del c
+    return {"roofline_prefill_attn": mk("rope_gather_kernel+prefill_attn_dma_kernel", ms_a, fl_a, {"query_rows": T, "keys": L, "q_heads": Hq, "kv_heads": Hkv}),
+            "roofline_prefill_gemm": mk("gemm_glds_kernel (qkv, o_proj, gate/up + SwiGLU, down_proj of one layer)", ms_g, fl_g, {"rows": T})}
 
 
 def roofline_pass(model, args, kv_len):
