@@ -294,6 +294,7 @@ def roofline_pass(model, args, kv_len):
     c.reserve(L + 1)
     c.commit(L)
     c.sync_device()
+    c.pool.normal_()                     # random rows: zero-filled operands read high (lower toggle rate -> higher clock)
     pos = torch.arange(L + 1, dtype=torch.int32, device=dev).repeat(3, 1)
     eng.pos3_dev[:, :L + 1].copy_(pos)
     o.mrope_table(eng.pos3_dev, eng.inv_freq, eng.rope_cs, 0, L + 1, tc.mrope_section)
@@ -367,6 +368,7 @@ def roofline_pass(model, args, kv_len):
     c2.reserve(Lp)
     c2.commit(Lp)
     c2.sync_device()
+    c2.pool.normal_()
     timed("rope_gather_kernel+prefill_attn_dma_kernel+flash_combine_kernel(prefill)", NL, NL, 2 * Lp * Hkv * D * 2 * 2 + 2 * T * Hq * D * 2,
           4.0 * T * (Lp - T / 2.0) * Hq * D,
           lambda: [o.prefill_attn(qkv[:, :qd], c2.pool, i, c2.slot_of_dev, eng.rope_cs, att, T, Lp, Hq, scale) for i in range(NL)])
@@ -442,7 +444,7 @@ def roofline_pass(model, args, kv_len):
     def long_point(hq, hkv, Lbig):
         cap = Lbig + 64
         slot = torch.arange(cap, dtype=torch.int32, device=dev)
-        rope = torch.zeros((cap, D), dtype=torch.bfloat16, device=dev)
+        rope = torch.randn((cap, D), device=dev).to(torch.bfloat16)
         ch = type(eng).pick_decode_chunk(cap, hkv)
         ws = o.decode_attn_ws(hq, cap, ch, dev)
         out = torch.empty(hq * D, dtype=torch.bfloat16, device=dev)
