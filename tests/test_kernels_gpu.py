@@ -74,6 +74,7 @@ def close(name, got, want, max_tol=2 ** -7, mean_tol=1e-3):
     # large M, long K: 128-row tiles on the 2-stage ring (the dense prefill's LLM passes), ragged in M and N
     (2100, 392, 2048, True, True, 0),
     (2048, 256, 2112, False, False, 1),
+    (2048, 3584, 3584, True, True, 0),      # 224 tiles of 256 x 128 = one round at 87 %: the 8-wave tile is picked on its own
 ])
 def test_gemm(ops, ref, M, N, K, bias, res, act):
     A, W = rnd((M, K), 1), rnd((N, K), 2, 0.05)
@@ -115,7 +116,7 @@ def test_gemm_norm_fused_reduce(ops, ref, M, N, K):
     assert float(d.max()) <= 2 ** -7 * float(want.float().abs().max()) and float((d > 0).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (590, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64), (2050, 192, 2048)])
+@pytest.mark.parametrize("M,I,K", [(290, 8960, 1536), (290, 18944, 3584), (590, 18944, 3584), (37, 104, 128), (130, 512, 256), (1, 64, 64), (2050, 192, 2048), (2048, 1792, 2048)])
 def test_gemm_swiglu_epilogue(ops, ref, M, I, K, monkeypatch):
     """ACT_SWIGLU: W = [gate rows; up rows]; every tile pairs 64 gate with the 64 matching up columns and applies
     bf16(bf16(silu(g)) * u) in its epilogue == GEMM to (M, 2I) followed by svlm_silu_mul, for both tile heights."""
