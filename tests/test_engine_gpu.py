@@ -160,6 +160,20 @@ def test_dense_prefill_then_live_stream():
     assert out["steps"] == 5 * 8
 
 
+def test_dense_prefill_one_long_pass_runs_two_query_blocks():
+    """A dense prefill whose prompt (13 chunks of 224 x 224 frames: ~1.1k rows) goes through in ONE pass: the prefill attention then runs
+    two query blocks per wave on 64-key super tiles (T >= 1024, no key splits) -- the configuration of the 4096-row passes of configs[4]
+    -- inside the engine, held to the same bars; live chunks follow under sink/window eviction."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    cfg = C.tiny()
+    sd = H.decisive_weights(cfg, size=224)
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=2048, max_new_tokens=8)
+    out = _compare(cfg, sd, 15, model, size=224, window=512, dense_prefill_chunks=13)
+    assert out["steps"] == 3 * 8
+    assert model._svlm_engine._last_cache.get_seq_length() <= 4 + 512 + 100
+
+
 def test_tiny_stream_structural():
     cfg, sd, model = _tiny_model()
     _compare(cfg, sd, 8, model, policy="structural", text_round=2, window_size=3, text_sink=4, text_sliding_window=8,
