@@ -160,7 +160,10 @@ extern "C" int svlm_gemv_bf16(const void* x, const void* W, int ldw, const void*
   SVLM_CHECK_ARG(y || y_f32, "svlm_gemv_bf16: no output buffer");
   hipStream_t s = (hipStream_t)stream;
   if (N <= 8192 && K >= 4096) {        // skinny output, long reduction (down_proj): split K over the workgroup's waves
-    gemv_bf16_ksplit_kernel<2><<<(N + 1) / 2, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
+#ifndef KS_ROWS
+#define KS_ROWS 2
+#endif
+    gemv_bf16_ksplit_kernel<KS_ROWS><<<(N + KS_ROWS - 1) / KS_ROWS, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                                                  (const bf16_t*)residual, (bf16_t*)y, y_f32, N, K, act);
     return svlm_check_launch("svlm_gemv_bf16(ksplit)");
   }
