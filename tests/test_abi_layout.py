@@ -39,8 +39,9 @@ def test_every_declared_symbol_is_exported_and_bound(built):
     assert exported == declared, f"library exports differ from the header: {set(exported) ^ set(declared)}"
     assert _lib.load().svlm_abi_version() == 1
     assert _lib.load().svlm_decode_attn_ws_bytes(12, 2716, 32) > 0        # pure host arithmetic, safe without a GPU
-    # rotated q / gathered k, v (bf16) + 7 key splits of fp32 (O, m, l) partials: 60 query tiles alone cannot fill 256 CUs
-    assert _lib.load().svlm_prefill_attn_ws_bytes(275, 2330, 12, 2) == (275 * 12 + 2 * 2 * 2330) * 256 + 7 * 275 * 12 * 130 * 4
+    # rotated q / gathered k, v (bf16) + 8 key splits of fp32 (O, m, l) partials: 60 query tiles alone cannot fill 256 CUs
+    # (flash_attn.hip aims at ~480 workgroups -> 8 splits of the 2B chunk)
+    assert _lib.load().svlm_prefill_attn_ws_bytes(275, 2330, 12, 2) == (275 * 12 + 2 * 2 * 2330) * 256 + 8 * 275 * 12 * 130 * 4
     # 252 query tiles: 2 splits; 700 tiles: none
     assert _lib.load().svlm_prefill_attn_ws_bytes(560, 4600, 28, 4) == (560 * 28 + 2 * 4 * 4600) * 256 + 2 * 560 * 28 * 130 * 4
     assert _lib.load().svlm_prefill_attn_ws_bytes(1600, 4600, 28, 4) == (1600 * 28 + 2 * 4 * 4600) * 256
