@@ -215,6 +215,31 @@ int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int 
                  void* stream);
 /* RMSNorm(x; ln_w) -> h[n] = silu(Wg[n] x) * (Wu[n] x), W = [gate(I) | up(I)] rows.  replaces: :200-201 (Qwen2MLP). */
 int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, const void* W, int ldw, void* h, int I, int K, void* stream);
+
+/* ---- persistent decode-layer tail: o_proj + residual -> RMSNorm -> gate/up + SwiGLU -> down_proj + residual -> (next layer's)
+ * RMSNorm -> QKV + bias + KV append, as ONE launch of one 4-wave workgroup per CU (csrc/dec_tail.hip).  The four all-to-all seams
+ * inside it are 8-byte {tag, 2 x bf16} granule hand-offs swept by one gatherer wave per workgroup; the weight stream runs ahead of
+ * every seam through a ring of register batches.  Same arithmetic and rounding points as svlm_gemv_bf16 (o_proj, down_proj),
+ * svlm_dec_gate_up and svlm_dec_qkv, which it replaces inside a decode step.
+ * replaces: the per-layer module calls of qwen2/language_forward.py:161 (o_proj), :196-202 (residual, post_attention_layernorm, Qwen2MLP,
+ * residual) and the next layer's :183,80-82 (input_layernorm, q/k/v_proj) + generate/streaming_cache.py:72-73 (cache append), i.e.
+ * the body of the per-layer loop at :278 between two attention calls.
+ *   ws: svlm_dec_tail_ws_bytes(H, I, n_layers) bytes = [256-B status block][one granule block per layer]; int status = ((int*)ws)[0] is
+ *       sticky: non-zero once any gatherer gave up its (bounded) spin -- results of that step are then invalid; the caller checks it once
+ *       per chunk and clears it.  svlm_dec_tail_reset zeroes the granule blocks (NOT the status) and must run once before the tails of
+ *       every decode step (a memset node at the head of the step's graph).
+ *   attn [qd], x [H] (in: residual stream, out: the layer's output), weights as in the per-op entry points.
+ *   ln1_next == NULL: last layer, no QKV phase (q_out / planes / slot_of unused).
+ *   grid: workgroups to launch, 0 = one per CU.  All of them must be able to become resident together (one 256-thread workgroup of
+ *       <= 256 VGPRs per CU always can); results do not depend on where they land.
+ *   stamps: NULL, or [grid][2][16] uint64 wall-clock stamps of the gatherer's and the first consumer's barrier passes (a profiling aid of
+ *       tools/dec_tail_bench.py). */
+long long svlm_dec_tail_ws_bytes(int H, int I, int n_layers); /* [host] */
+int svlm_dec_tail_reset(void* ws, int H, int I, int n_layers, void* stream);
+int svlm_dec_tail(const void* attn, void* x, const void* o_w, int ld_o, const void* ln2, const void* gu_w, int ld_gu, const void* down_w,
+                  int ld_down, const void* ln1_next, const void* qkv_w_next, int ld_qkv, const void* qkv_b_next, void* q_out,
+                  void* k_planes_next, void* v_planes_next, const int* slot_of, const int* len_dev, int len_host, int H, int I, int qd, int kd,
+                  int D, int n_slots, float eps, void* ws, int layer, int n_layers, int grid, void* stamps, void* stream);
 /* final RMSNorm -> last-row logits (fp32 copy of the bf16 value) -> penalty / suppression -> per-workgroup argmax
  * candidates in ws (>= svlm_dec_lm_head_ws_bytes(V)); svlm_argmax_finish picks the winner and feeds it back
  * (same state protocol as svlm_penalty_argmax).  replaces: qwen2/language_forward.py:315, qwen2/model_forward.py:243,

@@ -521,6 +521,53 @@ class HipOps:
         assert N % 2 == 0 and h.numel() == N // 2 and x.numel() == K == ln_w.numel()
         check(self.lib.svlm_dec_gate_up(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(h), N // 2, K, _stream()), "svlm_dec_gate_up")
 
+    # ---- persistent decode-layer tail (csrc/dec_tail.hip)
+    def dec_tail_ws(self, H, I, n_layers, device):
+        """Granule workspace of a decode step's tails: [256-B status block | one granule block per layer], zero-initialised."""
+        n = self.lib.svlm_dec_tail_ws_bytes(int(H), int(I), int(n_layers))
+        if n <= 0:
+            raise _lib.SvlmError(f"svlm_dec_tail_ws_bytes({H}, {I}, {n_layers}) -> {n}")
+        return torch.zeros(n // 8, dtype=torch.int64, device=device)
+
+    def dec_tail_reset(self, ws, H, I, n_layers):
+        _req(ws, torch.int64, "dec_tail_reset.ws", 1)
+        assert ws.numel() * 8 >= self.lib.svlm_dec_tail_ws_bytes(int(H), int(I), int(n_layers))
+        check(self.lib.svlm_dec_tail_reset(_ptr(ws), int(H), int(I), int(n_layers), _stream()), "svlm_dec_tail_reset")
+
+    def dec_tail(self, attn, x, o_w, ln2, gu_w, down_w, eps, ws, layer, n_layers, nxt=None, grid=0, stamps=None):
+        """One layer's tail.  `nxt` = (ln1, qkv_w, qkv_b, q_out, pool, layer_index, slot_of, qd, kd, length, len_dev) of the NEXT layer's
+        QKV phase, or None for the last layer."""
+        _req(attn, BF16, "dec_tail.attn", 1); _req(x, BF16, "dec_tail.x", 1); _req(o_w, BF16, "dec_tail.o_w", 2); _req(ln2, BF16, "dec_tail.ln2", 1)
+        _req(gu_w, BF16, "dec_tail.gu_w", 2); _req(down_w, BF16, "dec_tail.down_w", 2); _req(ws, torch.int64, "dec_tail.ws", 1)
+        H, qd = o_w.shape
+        I = gu_w.shape[0] // 2
+        assert gu_w.shape == (2 * I, H) and down_w.shape == (H, I) and attn.numel() == qd and x.numel() == H == ln2.numel()
+        assert ws.numel() * 8 >= self.lib.svlm_dec_tail_ws_bytes(H, I, int(n_layers)) > 0 and 0 <= layer < n_layers
+        if nxt is None:
+            args = (0, 0, 0, 0, 0, 0, 0, 0, 0, 0, H, I, qd, 0, 0, 0)
+        else:
+            ln1, qkv_w, qkv_b, q_out, pool, li, slot_of, qd2, kd, length, len_dev = nxt
+            _req(ln1, BF16, "dec_tail.ln1", 1); _req(qkv_w, BF16, "dec_tail.qkv_w", 2); _req(qkv_b, BF16, "dec_tail.qkv_b", 1)
+            _req(q_out, BF16, "dec_tail.q_out", 1); _req(slot_of, torch.int32, "dec_tail.slot_of", 1); _req(pool, BF16, "dec_tail.pool", 5)
+            _, _, Hkv, n_slots, D = pool.shape
+            assert qkv_w.shape == (qd2 + 2 * kd, H) and qkv_b.numel() == qd2 + 2 * kd and kd == Hkv * D and qd2 == qd
+            assert ln1.numel() == H and q_out.numel() >= qd
+            if len_dev is None:
+                assert 0 <= length < slot_of.numel()
+            kp, vp = self._planes(pool, li)
+            args = (_ptr(ln1), _ptr(qkv_w), qkv_w.stride(0), _ptr(qkv_b), _ptr(q_out), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(len_dev),
+                    int(length), H, I, qd, kd, D, n_slots)
+        check(self.lib.svlm_dec_tail(_ptr(attn), _ptr(x), _ptr(o_w), o_w.stride(0), _ptr(ln2), _ptr(gu_w), gu_w.stride(0), _ptr(down_w),
+                                     down_w.stride(0), *args, float(eps), _ptr(ws), int(layer), int(n_layers), int(grid), _ptr(stamps), _stream()),
+              "svlm_dec_tail")
+
+    @staticmethod
+    def dec_tail_views(ws, H, I, layer):
+        """(status, x' granules, h granules, x'' granules) of one layer's block, for tests: int64 views, low half = 2 x bf16, high = tag."""
+        per = ((H // 2 * 2 + I // 2) * 8 + 255) // 256 * 256 // 8
+        base = 32 + per * layer
+        return ws[:1], ws[base:base + H // 2], ws[base + H // 2:base + H // 2 + I // 2], ws[base + H // 2 + I // 2:base + H + I // 2]
+
     def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws, temperature=None, rng=None, state=None):
         """`temperature` + `rng` (uint32[2] seed on the device) + `state`: Gumbel-max temperature sampling in the candidates."""
         _req(x, BF16, "dec_lm_head.x", 1); _req(ln_w, BF16, "dec_lm_head.ln_w", 1); _req(W, BF16, "dec_lm_head.W", 2)
