@@ -60,6 +60,7 @@ def main():
                          "to sink+window and the stream continues live; reports prefill frames/s beside the steady rate")
     ap.add_argument("--prefill-chunks", type=int, default=300, help="dense_prefill: chunks piled into the opening forward (300 = 5 min)")
     ap.add_argument("--vit-fp8", action="store_true", help="vision tower Linears on the fp8 MFMA path (svlm_gemm_fp8; configs[4])")
+    ap.add_argument("--decode-tail", action="store_true", help="decode step on the persistent layer-tail kernel (svlm_dec_tail) instead of the per-op launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -98,7 +99,7 @@ def main():
     n_chunks = first_timed + args.steps + 1
     log(f"rank {rank}/{world}: building {cfg.name} random weights on {dev}")
     sd = random_state_dict(cfg, 0, dev)
-    model = S.StreamingQwen2VL(cfg, sd, dev, max_len=max_len, max_new_tokens=args.new_tokens, vit_fp8=args.vit_fp8)
+    model = S.StreamingQwen2VL(cfg, sd, dev, max_len=max_len, max_new_tokens=args.new_tokens, vit_fp8=args.vit_fp8, decode_tail=args.decode_tail)
     if dense:
         model._svlm_engine.section_events = []
     log("engine ready; staging the synthetic stream in HBM")
@@ -177,7 +178,8 @@ def main():
         "config": {"workload": f"{cfg.name} bf16, {args.size}x{args.size} @{args.fps:g}fps synthetic stream, KV sink={args.sink} "
                                f"window={args.window}, {args.new_tokens} {'greedy' if args.sampling == 'greedy' else 'sampled (' + args.sampling + ')'} tokens/chunk, one stream per GPU",
                    "frames_per_chunk": frames_per_chunk, "new_tokens_per_chunk": args.new_tokens, "kv_len_steady": kv_steady[0],
-                   "kv_fill_chunks": fill, "vit_passes_in_timed_region": args.steps, "parallelism": f"streams{world}"},
+                   "kv_fill_chunks": fill, "vit_passes_in_timed_region": args.steps, "parallelism": f"streams{world}",
+                   "decode_step": "persistent layer tail (svlm_dec_tail), 3 launches per layer" if args.decode_tail else "per-op launches, 6 per layer"},
         "per_gpu_frames_per_sec": [round(v, 3) for v in per_gpu_fps],
         # wall time of a chunk per generated token, the figure eval/efficiency/efficiency_test.py:87-99 reports
         "chunk_ms_per_token": round(1e3 * t_max / max(1, tokens), 4),

@@ -235,6 +235,7 @@ class _VitRun:
 class SvlmEngine:
     def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, max_len: int = 4096, max_new_tokens: int = 32,
                  decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None, kv_slack: float = 1.0, kv_page_tokens: int = 16,
+                 decode_tail: Optional[bool] = None,
                  vit_fp8: bool = False):
         if ops is None:
             from .ops import HipOps
@@ -303,6 +304,16 @@ class SvlmEngine:
         self.d_h = torch.zeros(tc.intermediate_size, dtype=BF16, device=dev)
         self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, 16 if self._fixed_chunk is None else self.decode_chunk, dev)
         self.d_sws = ops.sampling_ws(V, dev)
+        # decode-step structure: per-op launches (6 per layer), or the persistent layer tail (csrc/dec_tail.hip: o_proj -> gate/up ->
+        # down_proj -> next layer's QKV in ONE launch per layer, 3 launches per layer with the attention pair).  Measured slower than
+        # the per-op launches on MI355X (profiles/r03_dec_tail_*.json), so it is opt-in.
+        self.decode_tail = (os.environ.get("SVLM_DECODE_TAIL", "0") == "1") if decode_tail is None else bool(decode_tail)
+        self.tail_ws = None
+        if self.decode_tail:
+            if not hasattr(ops, "dec_tail"):
+                raise ValueError("decode_tail=True needs an ops backend with dec_tail (the HIP library)")
+            self.tail_ws = ops.dec_tail_ws(H, tc.intermediate_size, len(self.w.layers), dev)
+            self._tail_status_host = torch.zeros(1, dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
         self._vit_rope_cache = {}
         self._vis_stream = None            # side stream the NEXT chunk's ViT runs on while this chunk decodes
         self._vis_pending = None           # [pixel tensor, grid, event, features, unfinished _VitRun]
@@ -521,7 +532,21 @@ class SvlmEngine:
         kv_len = self.state[0:1]
         scale = 1.0 / math.sqrt(tc.head_dim)
         o.gather_rows(w.embed, None, self.tok_buf, self.d_x.view(1, H), idx_off=self.state[1:2])
-        for li, lw in enumerate(w.layers):
+        if self.decode_tail:
+            # 3 launches per layer: [attn split] [attn combine] [tail: o+res, norm+gate/up+SwiGLU, down+res, next layer's norm+QKV+append]
+            nl = len(w.layers)
+            o.dec_tail_reset(self.tail_ws, H, tc.intermediate_size, nl)
+            l0 = w.layers[0]
+            o.dec_qkv(self.d_x, l0["ln1"], tc.rms_eps, l0["qkv_w"], l0["qkv_b"], self.d_qkv, c.pool, 0, c.slot_of_dev, qd, kd, len_dev=kv_len)
+            for li, lw in enumerate(w.layers):
+                o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
+                              self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
+                nxt = None
+                if li + 1 < nl:
+                    ln = w.layers[li + 1]
+                    nxt = (ln["ln1"], ln["qkv_w"], ln["qkv_b"], self.d_qkv, c.pool, li + 1, c.slot_of_dev, qd, kd, 0, kv_len)
+                o.dec_tail(self.d_attn, self.d_x, lw["o_w"], lw["ln2"], lw["gu_w"], lw["down_w"], tc.rms_eps, self.tail_ws, li, nl, nxt=nxt)
+        for li, lw in enumerate(w.layers if not self.decode_tail else ()):
             o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
                       len_dev=kv_len)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
@@ -555,7 +580,7 @@ class SvlmEngine:
             self._decode_step_launch(c)
             self._sample_launch(1, fused=True)
             return
-        key = (c.serial, self._penalty, self._suppress is not None, self._sampling, self.decode_chunk, self._attn_len)
+        key = (c.serial, self._penalty, self._suppress is not None, self._sampling, self.decode_chunk, self._attn_len, self.decode_tail)
         hit = self._graphs.get(key)
         if hit is None:
             # capture once per (cache, sampling config); state is restored because capture does not execute
@@ -757,6 +782,8 @@ class SvlmEngine:
             self._tok_host[:max_new_tokens].copy_(self.tok_buf[:max_new_tokens], non_blocking=True)
             if on_device:
                 self._pos_status_host.copy_(self.pos_ws[:1], non_blocking=True)
+            if self.tail_ws is not None:
+                self._tail_status_host.copy_(self.tail_ws[:1], non_blocking=True)
             self._tok_ev.record()
             if next_vision is not None:      # decode replays are in the queue: now the host can spend its 3 ms on the ViT launches
                 self.vision_prefetch(*next_vision, after=ev_pre)
@@ -765,6 +792,10 @@ class SvlmEngine:
             toks = self._tok_host[:max_new_tokens].numpy().copy()
         else:                                                            # host-side test backend
             toks = self.tok_buf[:max_new_tokens].numpy().copy()
+        if self.tail_ws is not None and self.device.type == "cuda" and int(self._tail_status_host[0]) & 0xFFFFFFFF:
+            self.tail_ws[:1].zero_()
+            raise RuntimeError("decode tail: a hand-off wait gave up (status %d): the workgroups of a svlm_dec_tail launch were not all "
+                               "resident together; this chunk's tokens are invalid" % (int(self._tail_status_host[0]) & 0xFFFFFFFF))
         n_new = max_new_tokens
         for j, t in enumerate(toks):
             if int(t) in cfg.eos_token_ids:

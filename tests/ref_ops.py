@@ -237,6 +237,22 @@ class RefOps:
         I = W.shape[0] // 2
         h.copy_((F.silu(y[:, :I]) * y[:, I:])[0])
 
+    # persistent layer tail (csrc/dec_tail.hip) as the four ops it fuses
+    def dec_tail_ws(self, H, I, n_layers, device):
+        return torch.zeros(32, dtype=torch.int64)
+
+    def dec_tail_reset(self, ws, H, I, n_layers):
+        pass
+
+    def dec_tail(self, attn, x, o_w, ln2, gu_w, down_w, eps, ws, layer, n_layers, nxt=None, grid=0, stamps=None):
+        self.gemv(attn, o_w, residual=x, out=x)
+        h = torch.zeros(gu_w.shape[0] // 2, dtype=x.dtype)
+        self.dec_gate_up(x, ln2, eps, gu_w, h)
+        self.gemv(h, down_w, residual=x, out=x)
+        if nxt is not None:
+            ln1, qkv_w, qkv_b, q_out, pool, li, slot_of, qd, kd, length, len_dev = nxt
+            self.dec_qkv(x, ln1, eps, qkv_w, qkv_b, q_out, pool, li, slot_of, qd, kd, length=length, len_dev=len_dev)
+
     def dec_lm_head(self, x, ln_w, eps, W, logits, seen, penalty, suppress, ws, temperature=None, rng=None, state=None):
         logits.copy_(F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W)[0].float())
         self._pending = (logits, seen, penalty, suppress, temperature, rng)

@@ -117,6 +117,21 @@ def test_tiny_stream_sink_window():
     _compare(cfg, sd, 6, model)
 
 
+def test_tiny_stream_on_the_persistent_decode_tail():
+    """The same stream with the decode step built on svlm_dec_tail (3 launches per layer): the bars of every other stream, graph
+    replay included (the reset memset is a node of the step's graph)."""
+    import streaming_vlm_amd as S
+    cfg, sd, _ = _tiny_model()
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8, decode_tail=True)
+    assert model._svlm_engine.decode_tail
+    _compare(cfg, sd, 6, model)
+    eager = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8, decode_tail=True, use_graph=False)
+    a = H.run_engine_stream(model, 4, keep_logits=True)[3]
+    b = H.run_engine_stream(eager, 4, keep_logits=True)[3]
+    for x, y in zip(a, b):
+        assert x["ids"] == y["ids"] and all(torch.equal(u, v) for u, v in zip(x["logits"], y["logits"]))
+
+
 def test_tiny_qwen2_5_stream_sink_window_ragged_windows():
     """Qwen2.5-VL family: windowed RMSNorm/SwiGLU tower (112x84 frames -> ragged attention windows), float temporal M-RoPE."""
     cfg, sd, model = _tiny_model(family="qwen2_5", stream=dict(size=(112, 84)))
@@ -412,6 +427,17 @@ def test_full_size_2b_two_chunks_448():
     cfg = C.qwen2_vl_2b()
     sd = H.decisive_weights(cfg, size=448, max_new=4)
     model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8)
+    _compare(cfg, sd, 2, model, floor=False, size=448, window=256, max_new=4)
+
+
+def test_full_size_2b_two_chunks_448_on_the_persistent_decode_tail():
+    """Full-size Qwen2-VL-2B with the decode step on svlm_dec_tail: exact tokens, logits anchored on the fp32 truth."""
+    import streaming_vlm_amd as S
+    from streaming_vlm_amd import config as C
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    cfg = C.qwen2_vl_2b()
+    sd = H.decisive_weights(cfg, size=448, max_new=4)
+    model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=1024, max_new_tokens=8, decode_tail=True)
     _compare(cfg, sd, 2, model, floor=False, size=448, window=256, max_new=4)
 
 

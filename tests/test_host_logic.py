@@ -44,6 +44,21 @@ def test_engine_equals_oracle_and_golden_traces(tiny, golden_dir):
         assert len(res) == g["n_chunks"] and all(isinstance(r["response"], str) for r in res)
 
 
+def test_decode_tail_path_equals_per_op_path_on_the_host_backend(tiny):
+    """Engine sequencing of the persistent-tail decode step (QKV of layer 0, then [attention, tail] per layer, the tail computing the
+    NEXT layer's QKV): on the host backend the tail is the four ops it fuses, so tokens, logits and KV lengths must be identical."""
+    cfg, sd = tiny
+    sd = H.decisive_weights(cfg)
+    outs = []
+    for tail in (False, True):
+        model = _model(cfg, sd, decode_tail=tail)
+        res, trace, counts, log = H.run_engine_stream(model, 4, keep_logits=True)
+        outs.append((trace, [e["ids"] for e in log], [e["kv_len"] for e in log], [torch.stack(e["logits"]) for e in log]))
+    assert outs[0][:3] == outs[1][:3]
+    for a, b in zip(outs[0][3], outs[1][3]):
+        assert torch.equal(a, b)
+
+
 def test_default_structural_policy_trace(tiny, golden_dir):
     """Reference defaults (16 vision rounds, 16 text rounds, 512+512 previous-text): trace equals the oracle's."""
     cfg, sd = tiny
