@@ -299,7 +299,11 @@ def gen_full_size_vectors(which=("2b", "7b")):
     plans = {"2b": ("cfg1_2b_448_win2048", C.qwen2_vl_2b, dict(size=448, fps=1.0, policy="sink_window", sink=4, window=2048, max_new=20,
                                                               previous_text=""), 12),
              "7b": ("cfg2_7b_448_2fps", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=512, max_new=20,
-                                                           previous_text=""), 3)}
+                                                           previous_text=""), 3),
+             # BASELINE configs[2] AT SPEC: Qwen2-VL-7B, 448x448 @2 fps, sink 4 / window 4096, 20 tokens; ~295 rows per chunk, so the
+             # window fills at chunk 14 and the last four chunks each evict (about an hour of host time)
+             "7b_spec": ("cfg2_7b_448_2fps_win4096", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096,
+                                                                        max_new=20, previous_text=""), 18)}
     for key in which:
         name, mk, kw, n = plans[key]
         cfg = mk()
@@ -320,6 +324,9 @@ def gen_full_size_vectors(which=("2b", "7b")):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if "--full-only" in sys.argv:     # one full-size plan by key (2b / 7b / 7b_spec), nothing else re-minted
+        gen_full_size_vectors((sys.argv[sys.argv.index("--full-only") + 1],))
+        sys.exit(0)
     gen_reference_vectors()
     gen_hf_vectors()
     gen_hf_vectors_2_5()

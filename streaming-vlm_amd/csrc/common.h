@@ -153,6 +153,17 @@ __device__ __forceinline__ float svlm_gumbel_noise(const unsigned* __restrict__ 
   return -logf(-log1pf(-v));
 }
 
+// The product library takes NO behaviour from the environment.  The tuning switches of the launchers (tile shapes, split counts,
+// kernel variants, the timing-only DIAG builds of the decode attention) read it through svlm_env(), which returns nullptr unless the
+// library is the DIAGNOSTIC build (-DSVLM_TUNING: tools/build_diag_lib.py -> streaming-vlm_amd/build/libsvlm_hip_diag.so, loaded
+// through SVLM_LIB_PATH by the tools that sweep those switches).
+#include <stdlib.h>
+#ifdef SVLM_TUNING
+static inline const char* svlm_env(const char* name) { return getenv(name); }
+#else
+static inline const char* svlm_env(const char*) { return nullptr; }
+#endif
+
 void svlm_set_error(const char* fmt, ...);
 #define SVLM_CHECK_ARG(cond, ...)                    \
   do {                                               \

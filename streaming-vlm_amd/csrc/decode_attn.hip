@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
 // The K / V / cos / sin rows of pass p+1 are in flight (register double buffer, unconditional clamped loads) while pass p
 // is rotated, staged and multiplied; the slot indices of the whole range are fetched once into LDS.
 #define DA_LONG_MAX 512
+#ifdef SVLM_TUNING           // the multi-pass kernel and its DIAG variants live in the diagnostic build only (launch_split below)
 struct DaPass {
   u32x4_t k[4], v[4], c[4], s[4];
 };
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void decode_attn_long_kernel(
     if (d == 0) { ws_m[part + hq] = mn; ws_l[part + hq] = l; }
   }
 }
+#endif       // SVLM_TUNING
 
 // Streaming variant for long caches (chunk % 64 == 0): the multi-pass kernel above meets at two workgroup barriers per 64-key pass,
 // which leaves it latency-bound (built with no arithmetic at all it still needs 23 of its 30 us at 32k keys x 4 kv heads:
@@ -512,6 +514,13 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     // ---- V to the wave's slab (LDS operations of one wave are executed in order: no barrier)
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(Vw + (4 * i + fq) * DA_VLD + fr * 8) = b.v[i];
+    if (base + 16 > n_rows) {       // (wave-uniform) the tile that crosses the end of the cache: rows behind it come from clamped slots and
+                                    // may hold anything (a pool need not be zero-filled); their P is 0, but 0 x Inf / NaN is NaN in the MFMA
+      const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (base + 4 * i + fq >= n_rows) *reinterpret_cast<u32x4_t*>(Vw + (4 * i + fq) * DA_VLD + fr * 8) = z;
+    }
     f32x4_t sacc = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
@@ -695,13 +704,11 @@ template <int G>
 static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* kp, const bf16_t* vp, const int* slot_of,
                          const bf16_t* cs, const int* len_dev, int len_add, float* ws_m, float* ws_l, float* ws_acc, int Hq, int Hkv,
                          int n_slots, int chunk, float scale, int max_len) {
-  static const int diag = getenv("SVLM_DA_DIAG") ? atoi(getenv("SVLM_DA_DIAG")) : 0;
-  static const bool stream_k = getenv("SVLM_DA_STREAM") == nullptr || atoi(getenv("SVLM_DA_STREAM")) != 0;
-  if (chunk > 16 * DA_MAX_STEPS && stream_k && diag == 0 && chunk <= 64 * DA_STREAM_TPW) {
-    decode_attn_stream_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
-    return;
-  }
-  if (chunk > 16 * DA_MAX_STEPS) {
+#ifdef SVLM_TUNING
+  // diagnostic build only: the multi-pass long-cache kernel the streaming kernel replaced, and its timing-only DIAG variants
+  static const int diag = svlm_env("SVLM_DA_DIAG") ? atoi(svlm_env("SVLM_DA_DIAG")) : 0;
+  static const bool stream_k = svlm_env("SVLM_DA_STREAM") == nullptr || atoi(svlm_env("SVLM_DA_STREAM")) != 0;
+  if (chunk > 16 * DA_MAX_STEPS && !(stream_k && diag == 0)) {
     if constexpr (G == 6 || G == 7) {
       switch (diag) {
         case 1: decode_attn_long_kernel<G, 1><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
@@ -714,7 +721,13 @@ static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_
       }
     }
     decode_attn_long_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+    return;
   }
+#endif
+  // caches beyond 16 * DA_MAX_STEPS keys per workgroup: the barrier-free streaming kernel (chunk <= 64 * DA_STREAM_TPW = DA_LONG_MAX,
+  // checked by the caller); the bounded windows: the split kernel
+  if (chunk > 16 * DA_MAX_STEPS)
+    decode_attn_stream_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
   else
     decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
 }
@@ -744,7 +757,7 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
 #undef SVLM_DA_CASE
   int rc = svlm_check_launch("svlm_decode_attn_ropeload(split)");
   if (rc) return rc;
-  static const int force_ds = getenv("SVLM_DA_COMBINE_DS") ? atoi(getenv("SVLM_DA_COMBINE_DS")) : 0;
+  static const int force_ds = svlm_env("SVLM_DA_COMBINE_DS") ? atoi(svlm_env("SVLM_DA_COMBINE_DS")) : 0;
   const int ns_max = (max_len + chunk - 1) / chunk;
   // measured on MI355X (tools/decode_attn_sweep.py): column halves pay from ~64 splits (7B @ window 4096: 13.8 -> 12.3 us),
   // column quarters on 16 waves from ~200 (32k keys: 26.3 -> 22.8 us); below that the extra workgroups only add latency

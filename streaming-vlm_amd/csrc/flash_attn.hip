@@ -621,7 +621,7 @@ static void fa_prepare() {
   }
 }
 static int fa_groups(const char* env, int dflt) {
-  const char* e = getenv(env);
+  const char* e = svlm_env(env);
   const int v = e ? atoi(e) : dflt;
   return v == 2 ? 2 : 1;
 }
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(const float* __restr
 // tiles per split, at most 8.
 static inline int prefill_splits(int T, int L, int Hq) {
   const int base = ((T + 63) / 64) * Hq;
-  static const int force = getenv("SVLM_PREFILL_SPLITS") ? atoi(getenv("SVLM_PREFILL_SPLITS")) : 0;      // tuning aid
+  static const int force = svlm_env("SVLM_PREFILL_SPLITS") ? atoi(svlm_env("SVLM_PREFILL_SPLITS")) : 0;      // tuning aid
   if (force > 0) return force > 8 ? 8 : force;
   int ns = base > 0 ? (480 + base / 2) / base : 1;      // ~480 workgroups: the 2B chunk (60 query tiles) takes 8 splits (28.0 us per layer, 29.6 with 7)
   const int by_len = L / (4 * FA_KT);
@@ -783,12 +783,12 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   static const int ng = fa_groups("SVLM_PREFILL_FA_GROUPS", 1);
   // long prefills (the dense-frame forward of configs[4]: 4096-row passes over up to 83k keys) run two query blocks per wave;
   // a streaming chunk (T ~ 290) keeps the 64-row tiles, whose key splits fill the chip
-  static const int qb_env = getenv("SVLM_PREFILL_QB") ? atoi(getenv("SVLM_PREFILL_QB")) : 0;
+  static const int qb_env = svlm_env("SVLM_PREFILL_QB") ? atoi(svlm_env("SVLM_PREFILL_QB")) : 0;
   const int qb = qb_env > 0 ? qb_env : (T >= 1024 && ns == 1 ? 2 : 1);
-  static const bool use_dma = getenv("SVLM_PREFILL_NO_DMA") == nullptr;
+  static const bool use_dma = svlm_env("SVLM_PREFILL_NO_DMA") == nullptr;
   if (use_dma && ng != 2) {
     dim3 gridd((T + 64 * qb - 1) / (64 * qb), Hq, ns);
-    static const bool super_tiles = getenv("SVLM_PREFILL_NO_SUPER") == nullptr;      // 64-key super tiles: 818 -> 869 TFLOP/s at 4096 x 83k
+    static const bool super_tiles = svlm_env("SVLM_PREFILL_NO_SUPER") == nullptr;      // 64-key super tiles: 818 -> 869 TFLOP/s at 4096 x 83k
     if (qb == 2 && super_tiles)
       prefill_attn_dma_kernel<2, true><<<gridd, 256, 4 * PA_STAGE_B, st>>>(q_rot, (long)Hq * 128, 128, k_rot, v_lin, (long)L * 128, (bf16_t*)out, o_stride, 128,
                                                                          T, L, L - T, Hq, Hkv, scale, ns, part_o, part_ml);
@@ -835,7 +835,7 @@ extern "C" int svlm_vit_attn(const void* qkv, void* out, int n_seq, int seq_len,
   // two wave groups per workgroup (2 waves per SIMD share every staged K/V tile): 33 -> 24 us for the 1024-token frame; the
   // 64-token Qwen2.5 windows hold a single 64-key super tile and keep one group
   static const int ng_env = fa_groups("SVLM_VIT_FA_GROUPS", 0);
-  const int ng = getenv("SVLM_VIT_FA_GROUPS") ? ng_env : (seq_len >= 256 ? 2 : 1);
+  const int ng = svlm_env("SVLM_VIT_FA_GROUPS") ? ng_env : (seq_len >= 256 ? 2 : 1);
 #define SVLM_VIT_FA(D_, DP_, NG_)                                                                                           \
   do {                                                                                                                      \
     fa_prepare<D_, DP_, NG_>();                                                                                             \

@@ -623,7 +623,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       {4, 2048, 5120, 64, 4},      // merger mlp.2 -> 3B: 19.7 vs 21.5
   };
   bool plan_w8 = false, plan_ns2 = false;
-  if (getenv("SVLM_GEMM_NO_TABLE") == nullptr) {
+  if (svlm_env("SVLM_GEMM_NO_TABLE") == nullptr) {
     const int mb = (M + 63) / 64;
     for (const GemmPlan& p : kTunedPlans) {
       if (p.N == N && p.K == K && mb >= p.mb - 1 && mb <= p.mb + 1 && (p.splits == 1 || (ws != nullptr && (long long)p.splits * M * N * 4 <= ws_bytes))) {
@@ -639,16 +639,16 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
   // per CU -- 610-740 -> 710-820 TFLOP/s against the 64-row tiles (tools/gemm_big.py); K = 1280 (the ViT's batches) gains nothing
   // and 256 x 128 tiles (8 waves, one workgroup per CU) where their grid fills whole rounds of the 256 CUs: 7B down_proj 821 -> 927,
   // gate/up 820 -> 886 TFLOP/s; 7B qkv (576 tiles = 2.25 rounds) stays on the 128-row tiles
-  if (M >= 2048 && K >= 2048 && best_splits == 1 && getenv("SVLM_GEMM_NO_T128") == nullptr) {
+  if (M >= 2048 && K >= 2048 && best_splits == 1 && svlm_env("SVLM_GEMM_NO_T128") == nullptr) {
     const long long t256 = (long long)((M + 255) / 256) * gn;
     const long long rounds = (t256 + 255) / 256;
     best_bm = (t256 * 100 >= rounds * 256 * 85) ? 256 : 128;
   }
-  if (const char* force = getenv("SVLM_GEMM_BM")) {       // tuning aid
+  if (const char* force = svlm_env("SVLM_GEMM_BM")) {       // tuning aid
     const int fb = atoi(force);
     best_bm = (fb == 192 || fb == 320 || fb == 256) ? fb : (fb == 128 && M > 64 ? 128 : 64);
     plan_w8 = plan_ns2 = false;
-    if (const char* fs = getenv("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
+    if (const char* fs = svlm_env("SVLM_GEMM_SPLITS")) best_splits = atoi(fs) > 0 ? atoi(fs) : 1; else best_splits = 1;
     if ((long long)best_splits * M * N * 4 > ws_bytes || ws == nullptr || K < 1024) best_splits = 1;
   }
   if (swiglu) {                       // one K pass (the pairing happens in the epilogue), register budget of the 64/128-row tiles
@@ -679,7 +679,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
     }
     attr_done = true;
   }
-  const bool dma = (K % GEMM_BK == 0) && getenv("SVLM_GEMM_NO_DMA") == nullptr;
+  const bool dma = (K % GEMM_BK == 0) && svlm_env("SVLM_GEMM_NO_DMA") == nullptr;
   if (!dma && (bm == 192 || bm == 320 || bm == 256 || swiglu)) {
     svlm_set_error("svlm_gemm_bf16: tall tiles and SVLM_ACT_SWIGLU run on the LDS-DMA kernel only (K %% 64 == 0, SVLM_GEMM_NO_DMA unset)");
     return SVLM_EINVAL;
@@ -698,8 +698,8 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       }
       dma_attr_done = true;
     }
-    const bool tall_unsplit_ns2 = M >= 2048 || plan_ns2 || getenv("SVLM_GEMM_T128NS2") != nullptr;
-    static const bool w8_128 = getenv("SVLM_GEMM_W8") != nullptr;       // tuning aid: force the 8-wave 128 x 128 tile
+    const bool tall_unsplit_ns2 = M >= 2048 || plan_ns2 || svlm_env("SVLM_GEMM_T128NS2") != nullptr;
+    static const bool w8_128 = svlm_env("SVLM_GEMM_W8") != nullptr;       // tuning aid: force the 8-wave 128 x 128 tile
     if (bm == 128 && splits == 1 && !swiglu && (w8_128 || plan_w8)) {
       constexpr int DL = 3 * (128 + GEMM_BN) * 128;
       static bool w8s_done = false;
@@ -742,7 +742,7 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
       else
         gemm_glds_kernel<10, 2><<<grid, 256, DLDS10, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                                                   (bf16_t*)C, ldc, partial, M, N, K, kps, act, gm, gn, splits);
-    } else if (small && splits == 1 && getenv("SVLM_GEMM_NS3") == nullptr) {
+    } else if (small && splits == 1 && svlm_env("SVLM_GEMM_NS3") == nullptr) {
       // un-split 64-row tiles on a 2-stage ring: 48 KB of LDS, THREE workgroups per CU -- one tile in flight each, the others' MFMAs
       // cover its wait.  Measured against the 3-stage ring (72 KB, two per CU; tools/gemm_shapes.py shapes, MI355X): ViT fc1
       // 31.5 -> 26.6 us, prefill gate/up 36.5 -> 31.2 us, ViT qkv 21.4 -> 20.9 us; split-K shapes are unchanged and keep 3 stages.

@@ -222,8 +222,8 @@ extern "C" int svlm_gemm_fp8(const void* A8, int lda, const float* a_scale, cons
     if (splits > 8) splits = 8;
     while (splits > 1 && (long long)splits * M * N * 4 > ws_bytes) --splits;
   }
-  if (const char* fs = getenv("SVLM_GEMM8_SPLITS")) { const int v = atoi(fs); if (v >= 1 && (v == 1 || (ws && (long long)v * M * N * 4 <= ws_bytes))) splits = v; }
-  if (const char* fb = getenv("SVLM_GEMM8_BM")) { const int v = atoi(fb); if (v == 64 || v == 128) bm = v; }
+  if (const char* fs = svlm_env("SVLM_GEMM8_SPLITS")) { const int v = atoi(fs); if (v >= 1 && (v == 1 || (ws && (long long)v * M * N * 4 <= ws_bytes))) splits = v; }
+  if (const char* fb = svlm_env("SVLM_GEMM8_BM")) { const int v = atoi(fb); if (v == 64 || v == 128) bm = v; }
   if (norm_w != nullptr && splits == 1 && ws != nullptr && K >= 1024 && (long long)2 * M * N * 4 <= ws_bytes && N <= 4096) splits = 2;   // the reduce carries the norm
   int kps = K;
   if (splits > 1) {

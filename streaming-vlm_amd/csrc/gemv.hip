@@ -168,7 +168,7 @@ extern "C" int svlm_gemv_bf16(const void* x, const void* W, int ldw, const void*
     return svlm_check_launch("svlm_gemv_bf16(ksplit)");
   }
   // rows per wave: keep >= ~2 waves of work per SIMD on 256 CUs, amortise x over up to 4 rows
-  static const int force_rows = getenv("SVLM_GEMV_ROWS") ? atoi(getenv("SVLM_GEMV_ROWS")) : 0;     // tuning aid
+  static const int force_rows = svlm_env("SVLM_GEMV_ROWS") ? atoi(svlm_env("SVLM_GEMV_ROWS")) : 0;     // tuning aid
   if (force_rows == 4 || (force_rows == 0 && N >= 16384)) {
     gemv_bf16_kernel<4><<<(N + 15) / 16, 256, 0, s>>>((const bf16_t*)x, (const bf16_t*)W, ldw, (const bf16_t*)bias,
                                                      (const bf16_t*)residual, (bf16_t*)y, y_f32, N, K, act);

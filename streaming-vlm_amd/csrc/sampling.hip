@@ -214,6 +214,7 @@ __global__ __launch_bounds__(SF_THREADS) void sample_filtered_kernel(const float
       __syncthreads();
     }
     const unsigned above = sh_above;                   // keys strictly above the range this level splits
+    __syncthreads();                                   // every thread has read sh_above before the finder below rewrites it
     const unsigned k_cnt = (unsigned)min(k_eff + n_suppress, V);
     const unsigned want = k_cnt > above ? k_cnt - above : 1u;
     for (int i = tid; i < SF_BINS; i += SF_THREADS) {

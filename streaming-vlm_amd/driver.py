@@ -307,7 +307,9 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
             h, w = resized_shape(h, w, f0.shape[0])
         n_tok = ((f0.shape[0] + 1) // 2) * (h // 28) * (w // 28)
         n_prev = len(proc(text=previous_text)["input_ids"][0]) if previous_text else 0
-        return required_max_len(n_tok, max_new_tokens, kv_policy, window_size // chunk_duration, text_round, text_sink, text_sliding_window,
+        # the loop below evicts with visual_round = window_size (the reference's own quirk, inference.py:320: rounds, not seconds), so
+        # window_size rounds are retained whatever chunk_duration is
+        return required_max_len(n_tok, max_new_tokens, kv_policy, window_size, text_round, text_sink, text_sliding_window,
                                 sink, window, num_chunks, n_prev)
 
     if model is None or processor is None:
@@ -447,6 +449,8 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
             inputs["pixel_values_videos"] = torch.cat(dense_pix, dim=0)
             inputs["video_grid_thw"] = torch.cat(dense_grids, dim=0)
             dense_ids, dense_pix, dense_grids = [], [], []
+            # the piled chunks' clips are only ever looked at again by the recompute path, through the last window_size of them
+            del recent_video_window_clips[:max(0, len(recent_video_window_clips) - window_size)]
         if prev_generated_ids is not None:
             # the history ends with <|im_end|> (keep the new "\n") or already with "\n" (drop the duplicate)
             if int(prev_generated_ids[0, -1]) != TOKEN_IDS["\n"]:

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -285,6 +286,8 @@ class SvlmEngine:
             self._tok_host = torch.zeros(self.max_new + 1, dtype=torch.int32).pin_memory()
             self._pos_status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._tok_ev = torch.cuda.Event()
+            self._poll_host = [torch.zeros(self.max_new + 1, dtype=torch.int32).pin_memory() for _ in range(2)]      # EOS looks, one behind
+            self._poll_ev = [torch.cuda.Event(), torch.cuda.Event()]
         self.state = torch.zeros(2, dtype=torch.int32, device=dev)          # [kv_len, cur]
         self.seen = torch.zeros(V, dtype=torch.uint8, device=dev)
         self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
@@ -582,15 +585,22 @@ class SvlmEngine:
             return
         key = (c.serial, self._penalty, self._suppress is not None, self._sampling, self.decode_chunk, self._attn_len, self.decode_tail)
         hit = self._graphs.get(key)
+        if hit is not None and hit[1]() is not c:         # (a serial is never reused; belt and braces)
+            hit = None
         if hit is None:
             # capture once per (cache, sampling config); state is restored because capture does not execute
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._decode_step_launch(c)
                 self._sample_launch(1, fused=True)
+            # a graph holds raw pointers into its pool but must not keep the pool alive: modes that open a fresh cache per chunk
+            # (recompute, the efficiency harness's mode c) would otherwise pin max_graphs full pools.  Entries of pools that are gone
+            # are dropped here; a serial is unique, so a dead pool's graph can never be replayed.
+            for k in [k for k, v in self._graphs.items() if v[1]() is None]:
+                del self._graphs[k]
             if len(self._graphs) >= self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))          # oldest capture (and its pool reference) goes
-            hit = self._graphs[key] = (g, c)
+                self._graphs.pop(next(iter(self._graphs)))          # oldest capture goes
+            hit = self._graphs[key] = (g, weakref.ref(c))
         self._graph = hit[0]
         self._graph.replay()
 
@@ -761,21 +771,31 @@ class SvlmEngine:
             ev_pre = torch.cuda.Event()
             ev_pre.record()                 # the look-ahead ViT may start here: behind the prefill, beside the decode steps
         eos_poll = 0 if (suppress_eos or self.device.type != "cuda") else 4
+        poll, prefetched = None, False       # poll: (event, host buffer, token count) of the look that is still in flight
         for step in range(1, max_new_tokens):
             self._decode_step(cache)
             if keep_logits:
                 logits_out.append(self.logits.detach().cpu().clone())
             if own is not None:
                 self._force(step, force_tokens, own, seen_host)
-            # a real caption ends well before max_new_tokens: every 4th step the tokens so far are looked at (one small D2H + sync)
-            # and the remaining steps are not launched once an end-of-turn token is among them; with EOS suppressed (benchmarks:
-            # fixed token counts) nothing is polled and the chunk keeps its single host sync
+            # a real caption ends well before max_new_tokens: every 4th step the tokens so far are copied out, and the remaining steps
+            # are not launched once an end-of-turn token is among them.  The look is ONE POLL BEHIND: the copy queued at step s is read
+            # at step s + 4, when it has long landed, so the GPU never drains at a poll (at most 2 x 4 steps run past the EOS; their
+            # KV rows are rolled back with the rest, cache.commit below).  The look-ahead ViT is enqueued in front of the first poll,
+            # underneath the steps already queued -- not behind the whole loop, where it would no longer overlap anything.  With EOS
+            # suppressed (benchmarks: fixed token counts) nothing is polled and the chunk keeps its single host sync.
             if eos_poll and step % eos_poll == 0 and step + 1 < max_new_tokens:
-                self._tok_host[:step + 1].copy_(self.tok_buf[:step + 1], non_blocking=True)
-                self._tok_ev.record()
-                self._tok_ev.synchronize()
-                if any(int(t) in cfg.eos_token_ids for t in self._tok_host[:step + 1].tolist()):
-                    break
+                if next_vision is not None and not prefetched:
+                    self.vision_prefetch(*next_vision, after=ev_pre)
+                    prefetched = True
+                if poll is not None:
+                    poll[0].synchronize()
+                    if any(int(t) in cfg.eos_token_ids for t in poll[1][:poll[2]].tolist()):
+                        break
+                k = (step // eos_poll) & 1
+                self._poll_host[k][:step + 1].copy_(self.tok_buf[:step + 1], non_blocking=True)
+                self._poll_ev[k].record()
+                poll = (self._poll_ev[k], self._poll_host[k], step + 1)
         # the one host sync of the chunk waits for the TOKENS only: the held-back ViT tail of the look-ahead pass is enqueued
         # behind the copy and keeps the GPU busy while the host turns the chunk around
         if self.device.type == "cuda":
@@ -785,7 +805,7 @@ class SvlmEngine:
             if self.tail_ws is not None:
                 self._tail_status_host.copy_(self.tail_ws[:1], non_blocking=True)
             self._tok_ev.record()
-            if next_vision is not None:      # decode replays are in the queue: now the host can spend its 3 ms on the ViT launches
+            if next_vision is not None and not prefetched:      # decode replays are in the queue: now the host can spend its 3 ms on the ViT launches
                 self.vision_prefetch(*next_vision, after=ev_pre)
             self.vision_prefetch_finish()
             self._tok_ev.synchronize()

@@ -40,9 +40,16 @@ def streaming_generate(self, input_ids=None, attention_mask=None, pixel_values_v
                        return_dict_in_generate: bool = True, do_sample: bool = True, repetition_penalty: float = 1.0,
                        streaming_args: Optional[StreamingArgs] = None, pad_token_id=None, temperature: float = 1.0,
                        second_per_grid_ts=None, suppress_eos: bool = False, keep_logits: bool = False, generator=None, next_vision=None,
-                       force_tokens=None, top_k=None, top_p=None, **unused):
+                       force_tokens=None, top_k=None, top_p=None, pixel_values=None, image_grid_thw=None, **unknown):
     """Greedy / sampling generation on the HIP engine (reference: streaming_generate + _sample,
-    generate/streaming_generate_qwen.py:130-278, 8-127)."""
+    generate/streaming_generate_qwen.py:130-278, 8-127).  Keyword arguments this path does not implement are REFUSED, not dropped:
+    image inputs (qwen2/model_forward.py:36-50 embeds `pixel_values` / `image_grid_thw`; the streaming loop only ever sends
+    videos, inference.py:440-451) raise NotImplementedError, anything else a TypeError naming it."""
+    if pixel_values is not None or image_grid_thw is not None:
+        raise NotImplementedError("image inputs (pixel_values / image_grid_thw) are not supported by the streaming path: it takes "
+                                  "video frames only (pixel_values_videos / video_grid_thw), as the reference's streaming loop sends them")
+    if unknown:
+        raise TypeError(f"streaming generate() got unexpected keyword argument(s): {sorted(unknown)}")
     eng: SvlmEngine = self._svlm_engine
     if streaming_args is None:
         raise ValueError("streaming_args is required (reference: every forward reads streaming_args.pos_mode)")
@@ -92,9 +99,13 @@ def convert_qwen2_5_to_streaming(model, ops=None, **engine_kw):
     return model
 
 
-def convert_qwen2_to_streaming(model, ops=None, **engine_kw):
+def convert_qwen2_to_streaming(model, ops=None, keep_hf_weights: bool = False, **engine_kw):
     """Accepts an HF ``Qwen2VLForConditionalGeneration`` (weights are copied into the engine and
-    ``generate`` is rebound) or an already converted model (returned unchanged)."""
+    ``generate`` is rebound) or an already converted model (returned unchanged).
+    The engine holds its own (fused) copies of the weights; unless `keep_hf_weights`, the module's parameters are then re-pointed
+    at empty tensors so the originals do not stay in HBM beside them (2 x 15 GB on a 7B): tensors the engine took over without a
+    copy stay alive through the engine's own reference.  The module's HF forward is not usable afterwards -- like the reference's
+    conversion (11 re-bound methods, patch_model.py:18-34), the object exists to be driven through `generate(streaming_args=...)`."""
     if getattr(model, "_svlm_engine", None) is not None:
         return model
     cfg = from_hf_config(model.config)
@@ -117,4 +128,8 @@ def convert_qwen2_to_streaming(model, ops=None, **engine_kw):
             cfg.eos_token_ids = eos
             eng.eos_dev = torch.tensor(list(eos), dtype=torch.int32, device=eng.device)
     model.generate = MethodType(streaming_generate, model)
+    if not keep_hf_weights:
+        del sd
+        for prm in list(model.parameters()) + list(model.buffers()):
+            prm.data = torch.empty(0, dtype=prm.dtype, device=prm.device)
     return model

@@ -53,6 +53,16 @@ def test_header_cites_the_reference_for_every_entry_point():
     assert "language_forward.py" in txt and "vision_forward.py" in txt and "streaming_cache.py" in txt and "inference.py" in txt
 
 
+def test_product_library_takes_no_behaviour_from_the_environment(built):
+    """Tuning switches (SVLM_GEMM_BM, SVLM_DA_DIAG, ...) and the timing-only DIAG kernels exist in the diagnostic build only
+    (-DSVLM_TUNING, tools/build_diag_lib.py): the product library neither imports getenv nor carries a switch name."""
+    nm = subprocess.run(["nm", "-D", "--undefined-only", built], capture_output=True, text=True).stdout
+    assert "getenv" not in nm
+    blob = open(built, "rb").read()
+    assert b"SVLM_DA_DIAG" not in blob and b"SVLM_GEMM_BM" not in blob and b"SVLM_PREFILL_SPLITS" not in blob
+    assert b"decode_attn_long_kernel" not in blob
+
+
 def test_library_targets_gfx950_only(built):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built], capture_output=True, text=True).stdout
     archs = set(re.findall(r"gfx[0-9a-f]+", out))

@@ -123,6 +123,12 @@ def test_error_behaviour(tiny):
         m._svlm_engine.generate([151652, 151656, 151653, 5], None, [[1, 4, 4]], torch.zeros(16, 1176), [[1, 4, 4]], max_new_tokens=2)
     with pytest.raises(MemoryError):
         m._svlm_engine.generate(list(range(10, 1100)), None, [], max_new_tokens=2)
+    # keyword arguments the path does not implement are refused, not dropped: image inputs (qwen2/model_forward.py:36-50) and typos
+    args = dict(input_ids=torch.tensor([[1, 2, 3]]), streaming_args=S.StreamingArgs("shrink"), max_new_tokens=2)
+    with pytest.raises(NotImplementedError):
+        m.generate(pixel_values=torch.zeros(4, 1176), image_grid_thw=torch.tensor([[1, 2, 2]]), **args)
+    with pytest.raises(TypeError, match="temperatur"):
+        m.generate(temperatur=0.5, **args)
 
 
 # ----------------------------------------------------------------------------- KV pool
@@ -310,6 +316,11 @@ def test_cli_mirrors_the_reference_flags(tiny, tmp_path, monkeypatch, capsys):
     out = drv._cli(["--model_path", "random:tiny", "--model_base", "Qwen2", "--video_path", "synthetic://56x56@1fps", "--duration", "19",
                     "--output_dir", str(tmp_path / "d.vtt"), "--quiet", "--greedy"])
     assert len(out) == 19 and built[-1] is not None and built[-1] < 4096, built
+    # two-second chunks: the loop retains window_size ROUNDS (inference.py:320), so an engine sized for window_size // chunk_duration
+    # rounds would overflow once more than that many chunks are retained
+    out = drv._cli(["--model_path", "random:tiny", "--model_base", "Qwen2", "--video_path", "synthetic://56x56@1fps", "--duration", "16",
+                    "--chunk_duration", "2", "--window_size", "4", "--text_round", "4", "--output_dir", str(tmp_path / "e.vtt"), "--quiet", "--greedy"])
+    assert len(out) == 8 and out[-1]["end_time"] == 16
 
 
 def test_required_max_len_bounds_every_golden_stream(golden_dir):

@@ -319,6 +319,15 @@ def test_decode_attn(ops, ref, Hq, Hkv, L, chunk):
     out2 = torch.empty_like(out)
     ops.decode_attn(q.cuda(), pg, 0, sg, rg, out2, ws, Hq, cap, chunk, scale, length=1, len_dev=len_dev)
     assert torch.equal(out2, out)
+    # rows the sequence does not map to may hold anything (a pool need not be zero-filled, pages are recycled): NaN in every slot
+    # outside slot_of[:L] must not reach the output (0 x NaN inside the P.V MFMA of a tile that crosses the end of the cache)
+    used = torch.zeros(pool.shape[3], dtype=torch.bool)
+    used[slot_of[:L].long()] = True
+    pn = pool.clone()
+    pn[:, :, :, ~used] = float("nan")
+    out3 = torch.empty_like(out)
+    ops.decode_attn(q.cuda(), pn.cuda(), 0, sg, rg, out3, ws, Hq, cap, chunk, scale, length=L)
+    assert torch.equal(out3, out), "stale / non-finite pool rows behind the end of the sequence leak into the output"
 
 
 # (2,1,700,700) and (4,2,300,1000) run 5 / 7 key splits whose last ones start beyond some queries' causal limit (rows that
@@ -605,6 +614,34 @@ def test_penalty_sample_distribution(ops, V, temperature, top_k, top_p, penalty)
     assert counts[probs == 0].sum() == 0, "a draw fell outside the survivor set"
     p, cells = _chi2_p(counts, probs, N)
     print(f"[sample V={V} T={temperature} k={top_k} p={top_p}] {cells} cells, chi-square p = {p:.3g}, support {int((probs > 0).sum())}")
+    assert p > 1e-4, p
+
+
+def test_penalty_sample_multi_level_radix_descent(ops):
+    """top-k over 20000 scores that all fall into ONE 11-bit radix bin (same exponent, same two leading mantissa bits): the candidate
+    range has to be narrowed by the second and third level of the descent.  Every thread must use the same `above` count at each level
+    (a workgroup barrier separates its read from the finder's update): a thread that saw the updated count would pick a higher bin, the
+    list would hold fewer than k candidates and the draw would come from a truncated top-k set -- caught here by the distribution
+    test over the oracle's top-k survivors."""
+    from oracle import generate as og
+    V, N, top_k, T = 20000, 60_000, 50, 0.9
+    g = torch.Generator().manual_seed(77)
+    logits = 8.0 + torch.rand(V, generator=g) * 0.99                 # [8, 8.99): one quarter-octave
+    probs = torch.softmax(og.warp_scores(logits.clone(), T, top_k, 1.0), dim=-1).double().numpy()
+    assert int((probs > 0).sum()) == top_k
+    d_logits = logits.cuda()
+    tok_buf = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+    state = torch.tensor([0, -1], dtype=torch.int32, device="cuda")
+    rng = torch.tensor([4242, 17], dtype=torch.int32, device="cuda")
+    ws = ops.sampling_ws(V, "cuda")
+    for _ in range(N):
+        ops.penalty_sample(d_logits, None, 1.0, None, T, top_k, 1.0, rng, tok_buf, state, 0, ws)
+    torch.cuda.synchronize()
+    counts = np.bincount(tok_buf[:N].cpu().numpy(), minlength=V).astype(np.float64)
+    assert counts[probs == 0].sum() == 0, "a draw fell outside the top-k set"
+    assert int((counts > 0).sum()) == top_k, "some of the k survivors were never drawn: truncated candidate list"
+    p, cells = _chi2_p(counts, probs, N)
+    print(f"[sample multi-level] {cells} cells, chi-square p = {p:.3g}")
     assert p > 1e-4, p
 
 
