@@ -7,9 +7,11 @@ LLM prefill of the chunk's ~275 new tokens -> 20 greedy decode tokens, through
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model 2b|7b|tiny]
 
-N > 1 is launched by the driver with torch.distributed.run: one independent stream per rank, RCCL
-barrier only around the timed region (streams never interact -> "weak" scaling).
-Prints ONE JSON line on rank 0.
+N > 1: one independent stream per rank, RCCL barrier only around the timed region (streams never
+interact -> "weak" scaling).  Launched by the driver with torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in
+the environment), or -- when `--gpus N` is given WITHOUT such an environment -- by bench.py itself: it starts N
+children (one per device, rendezvous on 127.0.0.1) before anything touches a GPU and forwards rank 0's line.
+A WORLD_SIZE that disagrees with `--gpus` is refused.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -34,6 +36,32 @@ _T0 = time.perf_counter()
 def log(msg):
     """progress on stderr (stdout carries only the one JSON line)"""
     print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def self_launch(n: int) -> int:
+    """`--gpus N` without a launcher: N children of this same command line, RANK = LOCAL_RANK = 0..N-1, rendezvous on localhost
+    (the pattern of eval/livesports3kcc/distributed_generate_streaming.py:127-143: one process per device).  Nothing here touches
+    a GPU.  Rank 0's stdout is this process's stdout; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
+# BASELINE.json configs by number (0 is the CPU plumbing case of the parity tests, not a bench line)
+CONFIGS = {1: dict(model="2b", fps=1.0, window=2048), 2: dict(model="7b", fps=2.0, window=4096), 3: dict(model="7b", fps=2.0, window=4096),
+           4: dict(model="7b", fps=2.0, window=4096, scenario="dense_prefill")}
 
 
 def main():
@@ -63,7 +91,34 @@ def main():
     ap.add_argument("--decode-tail", action="store_true", help="decode step on the persistent layer-tail kernel (svlm_dec_tail) instead of the per-op launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra-values", action="store_true", help="skip the strict-causal / PCIe-inclusive / EOS-polling passes behind the contract's run")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=None,
+                    help="BASELINE.json configs[n]: 1 = the default line (2B, 1 fps, window 2048); 2 = 7B, 2 fps, window 4096; 3 = config 2 as "
+                         "N independent streams (use with --gpus 8); 4 = config 2's model opened by the 5-minute dense prefill")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous + aggregation only (no model, no GPU work): what the CPU test of the "
+                                                          "self-launcher runs; prints the ranks the collective saw")
     args = ap.parse_args()
+    if args.config is not None:
+        for k, v in CONFIGS[args.config].items():
+            setattr(args, k, v)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))            # before anything touches a GPU
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}; refusing to report a line for the wrong job size")
+    if args.dry_run:
+        from streaming_vlm_amd import multi_stream as MS
+        dist, rank, world, local_rank = MS.init_distributed("gloo" if not torch.cuda.is_available() else os.environ.get("SVLM_DIST_BACKEND", "nccl"))
+        MS.fence(dist)
+        agg = MS.aggregate(1.0, 1.0, 1.0, dist, "cpu" if (dist is None or dist.get_backend() == "gloo") else torch.device("cuda", local_rank))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks_seen": agg["world"], "per_gpu_frames_per_sec": agg["per_rank_frames_per_sec"]}), flush=True)
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -181,6 +236,9 @@ def main():
                    "kv_fill_chunks": fill, "vit_passes_in_timed_region": args.steps, "parallelism": f"streams{world}",
                    "decode_step": "persistent layer tail (svlm_dec_tail), 3 launches per layer" if args.decode_tail else "per-op launches, 6 per layer"},
         "per_gpu_frames_per_sec": [round(v, 3) for v in per_gpu_fps],
+        "per_gpu_min": round(min(per_gpu_fps), 3), "per_gpu_max": round(max(per_gpu_fps), 3),
+        "per_gpu_stdev": round((sum((v - sum(per_gpu_fps) / len(per_gpu_fps)) ** 2 for v in per_gpu_fps) / len(per_gpu_fps)) ** 0.5, 4),
+        "ranks_seen": agg["world"],          # ranks the collective (RCCL) gathered from: must equal n_gpus
         # wall time of a chunk per generated token, the figure eval/efficiency/efficiency_test.py:87-99 reports
         "chunk_ms_per_token": round(1e3 * t_max / max(1, tokens), 4),
         "kv_pool": {k: int(v) for k, v in cache_stats.items()},
@@ -204,6 +262,38 @@ def main():
         d = [1e3 * (b - a) for a, b in zip(stamps[first_timed:first_timed + args.steps], stamps[first_timed + 1:first_timed + args.steps + 1])]
         out["ms_per_step_first100"], out["ms_per_step_last100"] = round(sum(d[:100]) / 100, 3), round(sum(d[-100:]) / 100, 3)
 
+    # ---- the same stream under the three conditions the contract's `value` excludes (N = 1 only; each its own timed pass of K chunks
+    # on the same engine): strict-causal (no look-ahead ViT: chunk i+1's frames are not touched before chunk i is answered),
+    # PCIe-inclusive (uint8 frames from pinned host memory, H2D + patchify inside the timed region), and with EOS live (tokens polled
+    # every 4th step, the path every real captioning run takes; random weights almost never emit EOS, so the token count is the same)
+    if world == 1 and not dense and not args.no_extra_values:
+        def extra_pass(lookahead=True, ingest=args.ingest, suppress_eos=True):
+            n2 = fill + 3 + args.steps + 1
+            first2 = fill + 3
+            if ingest == "host":
+                v2, p2 = PinnedVideo(n2 + 1, args.size, args.fps, rank, period=128 if n2 > 256 else 0), DeviceFrameProcessor(model._svlm_engine.ops, dev)
+            else:
+                v2, p2 = ResidentVideo(n2 + 1, args.size, args.fps, rank, dev, period=128 if n2 > 256 else 0), ResidentProcessor()
+            tt, cnt = {}, []
+
+            def cb(i):
+                if i == first2 or i == first2 + args.steps:
+                    torch.cuda.synchronize()
+                    tt[i] = time.perf_counter()
+            S.streaming_inference(model=model, processor=p2, video=v2, model_base="Qwen2_5" if cfg.family == "qwen2_5" else "Qwen2",
+                                  duration=n2, previous_text="", kv_policy="sink_window", sink=args.sink, window=args.window,
+                                  do_sample=args.sampling != "greedy", temperature=0.9,
+                                  top_k={"greedy": None, "temperature": 0, "hf-default": 50}[args.sampling], top_p=1.0,
+                                  max_new_tokens=args.new_tokens, suppress_eos=suppress_eos, quiet=True, token_counts=cnt, chunk_callback=cb,
+                                  vision_lookahead=lookahead)
+            torch.cuda.synchronize()
+            dt = tt[first2 + args.steps] - tt[first2]
+            return round(args.steps * v2.frames_per_chunk / dt, 3), round(sum(cnt[first2:first2 + args.steps]) / dt, 2)
+        log("extra passes: strict-causal, PCIe-inclusive, EOS polling")
+        out["value_no_lookahead"], out["decode_tokens_per_sec_no_lookahead"] = extra_pass(lookahead=False)
+        if args.ingest != "host":
+            out["value_ingest_host"], _ = extra_pass(ingest="host")
+        out["value_eos_polling"], out["decode_tokens_per_sec_eos_polling"] = extra_pass(suppress_eos=False)
     if rank == 0 and not args.no_roofline:
         log("roofline pass (eager launches bracketed by HIP events)")
         out.update(roofline_pass(model, args, kv_steady[0]))
@@ -305,13 +395,13 @@ def roofline_pass(model, args, kv_len):
     scale = 1.0 / math.sqrt(D)
     results = []
 
-    def timed(name, launches, per_chunk, nbytes, flops, fn, reps=3):
+    def timed(name, launches, per_chunk, nbytes, flops, fn, reps=5):
         fn()                                     # warm: lazy workspaces are allocated outside the capture
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()               # replay from a HIP graph: Python cannot launch 5-us kernels back-to-back
         with torch.cuda.graph(g):
             fn()
-        best = None
+        tms = []
         for _ in range(reps):
             flush.fill_(1)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -319,10 +409,10 @@ def roofline_pass(model, args, kv_len):
             g.replay()
             e.record()
             torch.cuda.synchronize()
-            ms = s.elapsed_time(e)
-            best = ms if best is None else min(best, ms)
-        us = 1e3 * best / launches
-        r = {"kernel": name, "avg_us": round(us, 2), "launches_per_chunk": per_chunk, "ms_per_chunk": round(us * per_chunk / 1e3, 3)}
+            tms.append(s.elapsed_time(e))
+        us = 1e3 * (sum(tms) / len(tms)) / launches           # MEAN of the cold replays (the fastest one is kept beside it)
+        r = {"kernel": name, "avg_us": round(us, 2), "min_us": round(1e3 * min(tms) / launches, 2), "launches_per_chunk": per_chunk,
+             "ms_per_chunk": round(us * per_chunk / 1e3, 3)}
         if nbytes:
             r["bytes_per_launch"] = int(nbytes)
             r["GBps"] = round(nbytes / us / 1e3, 1)
@@ -458,16 +548,16 @@ def roofline_pass(model, args, kv_len):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()
-        best = None
-        for _ in range(3):
+        ts = []
+        for _ in range(5):
             flush.fill_(1)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             g.replay()
             e.record()
             torch.cuda.synchronize()
-            t = s.elapsed_time(e) / len(pools)
-            best = t if best is None else min(best, t)
+            ts.append(s.elapsed_time(e) / len(pools))
+        best = sum(ts) / len(ts)                 # mean over the cold replays
         nb = 2 * Lbig * hkv * D * 2 + Lbig * 3 * 4
         return {"kv_len": Lbig, "q_heads": hq, "kv_heads": hkv, "keys_per_workgroup": ch, "avg_launch_us": round(best * 1e3, 2),
                 "achieved": round(nb / best / 1e6, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(nb / best / 1e6 / HBM_PEAK_GBS, 4),

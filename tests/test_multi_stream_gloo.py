@@ -70,6 +70,21 @@ def test_two_ranks_independent_streams(tmp_path):
     assert res[0]["logs"]["0"] != res[1]["logs"]["1"]
 
 
+def test_bench_gpus_2_launches_itself_and_refuses_a_wrong_world_size():
+    """`python bench.py --gpus 2` WITHOUT a launcher starts its two ranks itself (before any GPU call) and the collective sees both;
+    a WORLD_SIZE that disagrees with --gpus is refused.  (--dry-run: rendezvous + aggregation only -- the hot path has no CPU form.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["per_gpu_frames_per_sec"]) == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="4", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=4" in bad.stderr
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["ranks_seen"] == 1
+
+
 def test_single_process_aggregate_and_shard():
     sys.path.insert(0, ROOT)
     from streaming_vlm_amd import multi_stream as MS
