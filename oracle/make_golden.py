@@ -282,6 +282,41 @@ def gen_oracle_vectors():
     print("oracle vectors:", {k: v["min_margin"] for k, v in runs.items()})
 
 
+RESIZE_CASES = [(100, 80, 56, 42), (37, 53, 28, 28), (90, 120, 28, 56), (30, 40, 56, 70), (64, 64, 64, 64)]
+RESIZE_AXES = [(640, 448), (360, 252), (1280, 448), (320, 448), (53, 28)]
+
+
+def resize_case_input(H, W, h, w):
+    g = torch.Generator().manual_seed(H * 7 + w)
+    x = torch.randint(0, 256, (2, 3, H, W), generator=g, dtype=torch.uint8)
+    x[1] = (torch.arange(W).view(1, 1, W) * 255 // max(W - 1, 1) + torch.arange(H).view(1, H, 1)).clamp(0, 255).to(torch.uint8)   # smooth ramp: many exact ties
+    return x
+
+
+def gen_resize_vectors():
+    """tests/golden/resize_torch_cpu.npz: what the INSTALLED torch's CPU kernel returns for the reference's resize call
+    (F.interpolate(x.float(), size, mode="bicubic", antialias=True, align_corners=False), the call under torchvision's v1
+    transforms.functional.resize): fp32 outputs of seeded clips, and the tap weights of whole axes read off one-hot rows."""
+    import torch.nn.functional as F
+    out = {}
+    for (H, W, h, w) in RESIZE_CASES:
+        y = F.interpolate(resize_case_input(H, W, h, w).float(), size=(h, w), mode="bicubic", antialias=True, align_corners=False)
+        out[f"f32_{H}x{W}_{h}x{w}"] = y.numpy()
+    for (n_in, n_out) in RESIZE_AXES:
+        eye = torch.eye(n_in).view(1, 1, n_in, n_in)
+        wts = F.interpolate(eye, size=(n_in, n_out), mode="bicubic", antialias=True, align_corners=False)[0, 0].numpy().T      # [out][in]
+        nz = [np.nonzero(r)[0] for r in wts]
+        lo = np.array([r[0] for r in nz], np.int32)
+        K = max(int(r[-1] - r[0] + 1) for r in nz)
+        tab = np.zeros((n_out, K), np.float32)
+        for i, r in enumerate(nz):
+            tab[i, :r[-1] - r[0] + 1] = wts[i, r[0]:r[-1] + 1]
+        out[f"w_{n_in}_{n_out}"] = tab
+        out[f"lo_{n_in}_{n_out}"] = lo
+    np.savez_compressed(os.path.join(OUT, "resize_torch_cpu.npz"), torch_version=np.array(torch.__version__), **out)
+    print("resize vectors:", sorted(out)[:4], "...")
+
+
 def gen_full_size_vectors(which=("2b", "7b")):
     """FULL-size token streams (tests/golden/full_size_streams.json): the CPU oracle in bf16 on the decisive weights, minutes of
     host time each, so they are minted here once and replayed on the GPU without the oracle in the loop.
@@ -303,17 +338,31 @@ def gen_full_size_vectors(which=("2b", "7b")):
              # BASELINE configs[2] AT SPEC: Qwen2-VL-7B, 448x448 @2 fps, sink 4 / window 4096, 20 tokens; ~295 rows per chunk, so the
              # window fills at chunk 14 and the last four chunks each evict (about an hour of host time)
              "7b_spec": ("cfg2_7b_448_2fps_win4096", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096,
-                                                                        max_new=20, previous_text=""), 18)}
+                                                                        max_new=20, previous_text=""), 18),
+             # BASELINE configs[4] at the real 7B widths, mid-size: 32 chunks (64 frames, 8.8k prompt rows = three 4096-row prefill passes,
+             # four 8-grid ViT passes) piled into ONE forward, then 3 live chunks; the first live chunk compacts the cache to sink + window.
+             # Once with the bf16 tower, once with the fp8 tower recipe (oracle/model.py:linear_fp8; about an hour of host time each)
+             "7b_dense": ("cfg4_7b_dense32", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096, max_new=20,
+                                                                 previous_text="", dense_prefill_chunks=32), 35),
+             "7b_dense_fp8": ("cfg4_7b_dense32_fp8vit", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096, max_new=20,
+                                                                            previous_text="", dense_prefill_chunks=32), 35)}
     for key in which:
         name, mk, kw, n = plans[key]
         cfg = mk()
         sd = H.decisive_weights(cfg, size=kw["size"], max_new=kw["max_new"])
-        o = H.run_oracle_stream(cfg, sd, n, keep_logits=True, **kw)
+        from oracle import model as om
+        om.VIT_FP8 = key.endswith("_fp8")
+        try:
+            o = H.run_oracle_stream(cfg, sd, n, keep_logits=True, **kw)
+        finally:
+            om.VIT_FP8 = False
         mm = min(H.greedy_margins(o))
         assert mm >= 1.0, (name, mm)
         tops = [[round(float(lg[t]), 4) for lg, t in zip(lgs, gen)] for lgs, gen in zip(o["logits"], o["generated"])]
-        runs[name] = {"model": key, "kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"],
-                      "top_logit": tops, "min_margin": round(mm, 4), "max_len": kw["sink"] + kw["window"] + 2 * 320 + 64,
+        dense = kw.get("dense_prefill_chunks", 0)
+        runs[name] = {"model": key.split("_")[0], "vit_fp8": key.endswith("_fp8"), "kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"],
+                      "top_logit": tops, "min_margin": round(mm, 4),
+                      "max_len": max(kw["sink"] + kw["window"] + 2 * 320 + 64, 64 + dense * 300 + 2 * 320),
                       "torch": torch.__version__}
         print(name, "min margin", mm, "kv_len", o["kv_len"])
         del sd, o
@@ -324,6 +373,9 @@ def gen_full_size_vectors(which=("2b", "7b")):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if "--resize" in sys.argv:        # only the torch-CPU resize fixture
+        gen_resize_vectors()
+        sys.exit(0)
     if "--full-only" in sys.argv:     # one full-size plan by key (2b / 7b / 7b_spec), nothing else re-minted
         gen_full_size_vectors((sys.argv[sys.argv.index("--full-only") + 1],))
         sys.exit(0)
@@ -331,5 +383,6 @@ if __name__ == "__main__":
     gen_hf_vectors()
     gen_hf_vectors_2_5()
     gen_oracle_vectors()
+    gen_resize_vectors()
     if "--full" in sys.argv:          # minutes of CPU time and ~20 GB of RAM for the 7B
         gen_full_size_vectors()

@@ -1,26 +1,53 @@
 """TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): CPU restatement of the frame resize in front of the path.
 
-The reference resizes every decoded uint8 clip with torchvision's tensor resize, bicubic with antialiasing, before the HF
+The reference resizes every decoded uint8 clip with torchvision's v1 tensor resize, bicubic with antialiasing, before the HF
 processor sees it (livecc_utils/src/livecc_utils/video_process_patch.py:134-153: `smart_resize` to a multiple of 28 inside the
-pixel budget, then `transforms.functional.resize(video, [h, w], BICUBIC, antialias=True).float()`).  torchvision is absent
-here; its tensor path is `torch.nn.functional.interpolate(x.float(), size, mode="bicubic", antialias=True,
-align_corners=False)` followed by clamp(0, 255), round-half-even and the cast back to uint8.  The separable filter below
-restates torch's published helper formulas (`torch/include/ATen/native/hip/UpSample.cuh`, namespace upsample_antialias:
-`_compute_weights_span`, `_compute_weights`, `BicubicFilterFunctor`, `interpolate_aa_single_dim`), in fp32, width first then
-height.
+pixel budget, then `transforms.functional.resize(video, [h, w], BICUBIC, antialias=True).float()`).  v1 `resize` casts a uint8
+tensor to float32 and calls `torch.nn.functional.interpolate(x, size, mode="bicubic", antialias=True, align_corners=False)` -- the
+clip comes from decord on the host, so that is ATen's CPU kernel -- then clamps, rounds half to even and casts back.  (torch's
+native uint8 kernel, which transforms.v2 would take, is a different fixed-point filter: up to 12 grey levels away.)
 
-Pinning: tests/test_resize.py runs `F.interpolate` of the installed torch on CPU beside this file.  torch's CPU kernel sums the
-taps in an association that its headers do not publish, so the fp32 intermediate differs in the last bits and, after rounding
-to uint8, about 2 pixels in 100 000 differ by ONE level (never more); the test bounds exactly that.  The HIP kernel
-(svlm_resize_bicubic_aa_u8) follows THIS file's operation order and is compared bit for bit.
+The arithmetic lives in oracle/_c/resize_ref.c (plain C, compiled with gcc on first use into oracle/_build/): the float kernel's
+formulas with the C promotion rules of its source and the FMA contraction of its build, both established empirically against the
+installed torch (see that file's header).  Pinning: tests/test_resize.py requires EXACT equality with F.interpolate -- fp32 bits and
+rounded uint8 -- on every case, against the installed torch and a committed fixture of its outputs.  The HIP kernel
+(svlm_resize_bicubic_aa_u8) and the product's host tap-table function are compared with this file bit for bit.
 """
 from __future__ import annotations
 
+import ctypes
 import math
+import os
+import subprocess
 
 import numpy as np
 
 f32 = np.float32
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "_c", "resize_ref.c")
+_LIB = os.path.join(_HERE, "_build", "libresize_ref.so")
+_lib = None
+
+
+def build_c(force: bool = False) -> str:
+    """gcc -O2 -ffp-contract=off (every fma in the source is an explicit fmaf) -> oracle/_build/libresize_ref.so"""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", _LIB, _SRC, "-lm"])
+    return _LIB
+
+
+def _c():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(build_c())
+        ip, fp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+        lib.svlm_ref_aa_tables.restype = ctypes.c_int
+        lib.svlm_ref_aa_tables.argtypes = [ctypes.c_int, ctypes.c_int, ip, ip, fp, ctypes.c_int]
+        lib.svlm_ref_resize_rows.restype = None
+        lib.svlm_ref_resize_rows.argtypes = [fp, ctypes.c_long, ctypes.c_int, fp, ctypes.c_int, ip, ip, fp, ctypes.c_int]
+        _lib = lib
+    return _lib
 
 
 def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 100 * 28 * 28, max_pixels: int = 768 * 28 * 28):
@@ -41,49 +68,26 @@ def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 10
     return h_bar, w_bar
 
 
-def _cubic(x):
-    a = f32(-0.5)
-    x = abs(x)
-    if x < 1:
-        return ((a + f32(2)) * x - (a + f32(3))) * x * x + f32(1)
-    if x < 2:
-        return (((x - f32(5)) * x + f32(8)) * x - f32(4)) * a
-    return f32(0)
-
-
 def aa_tables(in_size: int, out_size: int):
-    """(xmin[out], xsize[out], weights[out][K]) of one axis; every operation in fp32, in this order."""
-    scale = f32(in_size) / f32(out_size)
-    support = f32(2.0) * scale if scale >= 1 else f32(2.0)
-    invscale = f32(1.0) / scale if scale >= 1 else f32(1.0)
-    K = int(math.ceil(float(support))) * 2 + 1
-    xmin = np.zeros(out_size, np.int32)
-    xsize = np.zeros(out_size, np.int32)
-    wt = np.zeros((out_size, K), f32)
-    for i in range(out_size):
-        center = scale * (f32(i) + f32(0.5))
-        lo = max(int(center - support + f32(0.5)), 0)
-        n = min(int(center + support + f32(0.5)), in_size) - lo
-        n = min(max(n, 0), K)
-        ws, tot = [], f32(0)
-        for j in range(n):
-            w = _cubic((f32(j + lo) - center + f32(0.5)) * invscale)
-            ws.append(w)
-            tot = tot + w
-        for j in range(n):
-            wt[i, j] = ws[j] / tot if tot != 0 else ws[j]
-        xmin[i], xsize[i] = lo, n
+    """(xmin[out], xsize[out], weights[out][K]) of one axis, as torch's CPU kernel computes them."""
+    lib = _c()
+    K = lib.svlm_ref_aa_tables(in_size, out_size, None, None, None, 0)
+    if K <= 0:
+        raise ValueError(f"aa_tables({in_size}, {out_size})")
+    xmin, xsize, wt = np.zeros(out_size, np.int32), np.zeros(out_size, np.int32), np.zeros((out_size, K), f32)
+    ip, fp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+    assert lib.svlm_ref_aa_tables(in_size, out_size, xmin.ctypes.data_as(ip), xsize.ctypes.data_as(ip), wt.ctypes.data_as(fp), K) == K
     return xmin, xsize, wt
 
 
 def _resize_last_axis(x: np.ndarray, out_size: int) -> np.ndarray:
+    lib = _c()
+    x = np.ascontiguousarray(x, dtype=f32)
     xmin, xsize, wt = aa_tables(x.shape[-1], out_size)
     out = np.zeros(x.shape[:-1] + (out_size,), f32)
-    for i in range(out_size):
-        acc = x[..., xmin[i]] * wt[i, 0]                         # fp32 product, then fp32 sums in tap order (no fused multiply-add)
-        for j in range(1, xsize[i]):
-            acc = acc + x[..., xmin[i] + j] * wt[i, j]
-        out[..., i] = acc
+    ip, fp = ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_float)
+    lib.svlm_ref_resize_rows(x.ctypes.data_as(fp), int(np.prod(x.shape[:-1], dtype=np.int64)), x.shape[-1], out.ctypes.data_as(fp), out_size,
+                             xmin.ctypes.data_as(ip), xsize.ctypes.data_as(ip), wt.ctypes.data_as(fp), wt.shape[1])
     return out
 
 

@@ -1,61 +1,59 @@
 // Frame ingest, first half: antialiased bicubic resize of uint8 frames.
 //
 // The reference resizes every decoded clip on the host before the processor sees it
-// (livecc_utils/src/livecc_utils/video_process_patch.py:134-153: torchvision's tensor resize, BICUBIC, antialias=True, on the
-// uint8 (T, C, H, W) clip).  torchvision's tensor path is torch's separable antialias filter in fp32 followed by clamp, round
-// half to even and the cast back to uint8; the tap tables below restate the helper formulas torch publishes in
-// ATen/native/(hip|cuda)/UpSample.cuh (namespace upsample_antialias).  Width pass first (uint8 -> fp32), height pass second
-// (fp32 -> uint8).  Both passes are plain HBM streams: one thread per output value, taps read through L1/L2, fp32 products
-// and sums in tap order WITHOUT fused multiply-add (the oracle's, i.e. an unfused CPU's, operation order).
+// (livecc_utils/src/livecc_utils/video_process_patch.py:134-153: torchvision's v1 tensor resize, BICUBIC, antialias=True, on the
+// uint8 (T, C, H, W) clip from decord).  v1 casts to float32 and runs torch's CPU antialias kernel
+// (aten/src/ATen/native/cpu/UpSampleKernel.cpp), then clamps, rounds half to even and casts back.  The arithmetic here is that
+// kernel's, bit for bit -- its formulas (cubic_convolution1 / 2 of ATen/native/UpSample.h:400-407), the double intermediates its
+// source's literals imply, and the FMA contraction of its build, all established against the installed torch (oracle/_c/resize_ref.c
+// tells how): weights = fma-contracted cubics normalised in fp32; every tap sum is t = src0 * w0, then t = fma(src_j, w_j, t) in tap
+// order; width pass first (uint8 -> fp32), height pass second (fp32 -> uint8).  Both passes are plain HBM streams: one thread per
+// output value, taps read through L1/L2.
 #include "common.h"
 
 #include <math.h>
 
+#pragma clang fp contract(off)      // every fused multiply-add below is an explicit fmaf
+
 static float resize_cubic(float x) {
-  const float a = -0.5f;
+  const float A = -0.5f;
   x = fabsf(x);
-  if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
-  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+  if (x < 1.f) return fmaf(fmaf(A + 2.f, x, -(A + 3.f)) * x, x, 1.f);
+  if (x < 2.f) return fmaf(fmaf(fmaf(A, x, -(5.f * A)), x, 8.f * A), x, -(4.f * A));
   return 0.f;
 }
 
 // Host arithmetic only (no GPU): tap tables of ONE axis.  Returns K, the row stride of `wt` (taps per output, incl. zero
 // padding), after filling xmin[out_size], xsize[out_size] and wt[out_size * K] when they are non-NULL (call once with NULL
-// pointers to size the buffers); negative on bad arguments.  Every operation is fp32, in the oracle's order.
+// pointers to size the buffers); negative on bad arguments.  (HelperInterpBase::_compute_indices_min_size_weights_aa with
+// scalar_t = float: the expressions with a double literal are evaluated in double and rounded where the source stores a float.)
 extern "C" int svlm_resize_aa_tables(int in_size, int out_size, int* xmin, int* xsize, float* wt, int wt_stride) {
   if (in_size <= 0 || out_size <= 0) return SVLM_EINVAL;
-  const volatile float scale = (float)in_size / (float)out_size;
-  const volatile float support = scale >= 1.f ? 2.0f * scale : 2.0f;
-  const volatile float invscale = scale >= 1.f ? 1.0f / scale : 1.0f;
+  const float scale = (float)in_size / (float)out_size;
+  const float support = scale >= 1.f ? (float)((4 * 0.5) * (double)scale) : (float)(4 * 0.5);
+  const float invscale = scale >= 1.f ? (float)(1.0 / (double)scale) : 1.0f;
   const int K = (int)ceilf(support) * 2 + 1;
   if (!xmin && !xsize && !wt) return K;
   if (!xmin || !xsize || !wt || wt_stride < K) return SVLM_EINVAL;
   for (int i = 0; i < out_size; ++i) {
-    const volatile float center = scale * ((float)i + 0.5f);
-    volatile float t = center - support;
-    t = t + 0.5f;
-    int lo = (int)t;
+    const float center = (float)((double)scale * ((double)i + 0.5));
+    long long lo = (long long)((double)(center - support) + 0.5);
     lo = lo > 0 ? lo : 0;
-    t = center + support;
-    t = t + 0.5f;
-    int hi = (int)t;
-    hi = hi < in_size ? hi : in_size;
-    int n = hi - lo;
+    long long n = (long long)((double)(center + support) + 0.5);
+    n = (n < in_size ? n : in_size) - lo;
     n = n < 0 ? 0 : (n > K ? K : n);
-    volatile float tot = 0.f;
+    float tot = 0.f;
     float* w = wt + (size_t)i * wt_stride;
     for (int j = 0; j < n; ++j) {
-      volatile float x = (float)(j + lo) - center;
-      x = x + 0.5f;
-      x = x * invscale;
-      w[j] = resize_cubic(x);
+      const float d = (float)(j + lo) - center;
+      w[j] = resize_cubic((float)(((double)d + 0.5) * (double)invscale));
       tot = tot + w[j];
     }
-    for (int j = 0; j < n; ++j)
-      if (tot != 0.f) w[j] = w[j] / tot;
-    for (int j = n; j < wt_stride; ++j) w[j] = 0.f;
-    xmin[i] = lo;
-    xsize[i] = n;
+    if (tot != 0.f)
+      for (int j = 0; j < n; ++j) w[j] = w[j] / tot;
+    for (int j = (int)n; j < wt_stride; ++j) w[j] = 0.f;
+    xmin[i] = (int)lo;
+    xsize[i] = (int)n;
   }
   return K;
 }
@@ -64,7 +62,6 @@ extern "C" int svlm_resize_aa_tables(int in_size, int out_size, int* xmin, int* 
 __global__ __launch_bounds__(256) void resize_aa_width_kernel(const unsigned char* __restrict__ src, float* __restrict__ tmp,
                                                               const int* __restrict__ xmin, const int* __restrict__ xsize,
                                                               const float* __restrict__ wt, int K, long long rows, int W, int w) {
-#pragma clang fp contract(off)      // the HIP __fmul_rn / __fadd_rn are plain operators: without this hipcc fuses them
   const int xo = blockIdx.x * 256 + threadIdx.x;
   if (xo >= w) return;
   const int n = xsize[xo];
@@ -73,10 +70,7 @@ __global__ __launch_bounds__(256) void resize_aa_width_kernel(const unsigned cha
   for (long long row = blockIdx.y; row < rows; row += gridDim.y) {
     const unsigned char* s = src + row * W + x0;
     float acc = (float)s[0] * wr[0];
-    for (int j = 1; j < n; ++j) {
-      const float p = (float)s[j] * wr[j];
-      acc = acc + p;
-    }
+    for (int j = 1; j < n; ++j) acc = fmaf((float)s[j], wr[j], acc);
     tmp[row * w + xo] = n > 0 ? acc : 0.f;
   }
 }
@@ -86,7 +80,6 @@ __global__ __launch_bounds__(256) void resize_aa_height_kernel(const float* __re
                                                                const int* __restrict__ ymin, const int* __restrict__ ysize,
                                                                const float* __restrict__ wt, int K, long long planes, int H, int h,
                                                                int w) {
-#pragma clang fp contract(off)
   const int xo = blockIdx.x * 256 + threadIdx.x;
   if (xo >= w) return;
   for (long long r = blockIdx.y; r < planes * h; r += gridDim.y) {
@@ -96,10 +89,7 @@ __global__ __launch_bounds__(256) void resize_aa_height_kernel(const float* __re
     const float* wr = wt + (size_t)yo * K;
     const int n = ysize[yo];
     float acc = s[0] * wr[0];
-    for (int j = 1; j < n; ++j) {
-      const float pr = s[(size_t)j * w] * wr[j];
-      acc = acc + pr;
-    }
+    for (int j = 1; j < n; ++j) acc = fmaf(s[(size_t)j * w], wr[j], acc);
     acc = n > 0 ? acc : 0.f;
     acc = fminf(fmaxf(acc, 0.f), 255.f);
     dst[r * w + xo] = (unsigned char)rintf(acc);

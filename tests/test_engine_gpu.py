@@ -341,7 +341,8 @@ def test_golden_full_size_streams_tokens_exact():
         kw = dict(g["kwargs"])
         cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b}[g["model"]]()
         sd = H.decisive_weights(cfg, size=kw["size"], max_new=kw["max_new"])
-        model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=g["max_len"], max_new_tokens=kw["max_new"])
+        model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=g["max_len"], max_new_tokens=kw["max_new"],
+                                   vit_fp8=bool(g.get("vit_fp8", False)))
         del sd
         _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], keep_logits=True, **kw)
         assert [[list(t) for t in c] for c in trace] == g["trace"], name

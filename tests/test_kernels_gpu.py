@@ -541,8 +541,9 @@ def test_fused_decode_kernels(ops, ref, H, Hq, Hkv, I, V):
 @pytest.mark.parametrize("T,H,W,h,w", [(2, 360, 640, 252, 448), (1, 240, 320, 336, 448), (3, 100, 80, 56, 42), (2, 64, 64, 64, 64),
                                        (1, 37, 53, 28, 28), (2, 720, 1280, 252, 448), (1, 30, 40, 56, 70), (1, 1080, 1920, 560, 1008)])
 def test_resize_bicubic_aa_u8_bit_exact(ops, T, H, W, h, w):
-    """svlm_resize_bicubic_aa_u8 == the oracle's fp32 separable antialias filter, bit for bit (down- and up-scaling, 5 to 13
-    taps per axis, identity at equal sizes); the oracle itself is pinned against torch's interpolate in tests/test_resize.py."""
+    """svlm_resize_bicubic_aa_u8 == the oracle's restatement of torch's CPU antialias kernel, bit for bit (down- and up-scaling, 5
+    to 13 taps per axis, identity at equal sizes) == torch.nn.functional.interpolate itself; the oracle is pinned to torch's fp32 bits
+    in tests/test_resize.py."""
     from oracle import resize as R
     g = torch.Generator().manual_seed(H * 3 + w + T)
     x = torch.randint(0, 256, (T, 3, H, W), generator=g, dtype=torch.uint8)
@@ -554,6 +555,9 @@ def test_resize_bicubic_aa_u8_bit_exact(ops, T, H, W, h, w):
     assert np.array_equal(got.cpu().numpy(), want)
     again = ops.resize_u8(x.cuda(), h, w)                 # cached tables, reused scratch
     assert torch.equal(again, got)
+    # and against the reference's own call on this box: torch's CPU antialias kernel in float32, clamp, round, cast (torchvision v1 resize)
+    ref = torch.nn.functional.interpolate(x.float(), size=(h, w), mode="bicubic", antialias=True, align_corners=False).clamp(0, 255).round().to(torch.uint8)
+    assert torch.equal(got.cpu(), ref), f"{int((got.cpu() != ref).sum())} pixels differ from torch's interpolate"
     with pytest.raises(Exception):
         ops.resize_u8(x.cuda().float(), h, w)
 

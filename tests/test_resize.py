@@ -1,39 +1,56 @@
-"""Frame resize in front of the path: oracle pinned against torch's own interpolate, host logic, and the host
-half of the C ABI (tap tables).  The kernel itself is compared with the oracle in tests/test_kernels_gpu.py."""
+"""Frame resize in front of the path: the oracle pinned TO THE BIT against torch's own CPU interpolate (the call
+under the reference's torchvision resize) -- live against the installed torch and against a committed fixture of its outputs --
+host logic, and the host half of the C ABI (tap tables).  The kernel itself is compared with the oracle in tests/test_kernels_gpu.py."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
 from oracle import resize as R
+from oracle.make_golden import RESIZE_AXES, RESIZE_CASES, resize_case_input
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize_torch_cpu.npz")
 
 
-def _torch_resize_u8(x: torch.Tensor, h: int, w: int) -> np.ndarray:
-    """torchvision's tensor resize(BICUBIC, antialias=True) on uint8: float32 interpolate, clamp, round, cast back."""
-    y = F.interpolate(x.float(), size=(h, w), mode="bicubic", antialias=True, align_corners=False)
-    return y.clamp(0, 255).round().to(torch.uint8).numpy()
+def _torch_f32(x: torch.Tensor, h: int, w: int) -> np.ndarray:
+    """what torchvision's v1 tensor resize(BICUBIC, antialias=True) computes for a uint8 clip before it rounds: float32 interpolate"""
+    return F.interpolate(x.float(), size=(h, w), mode="bicubic", antialias=True, align_corners=False).numpy()
 
 
 @pytest.mark.parametrize("H,W,h,w", [(360, 640, 252, 448), (240, 320, 336, 448), (100, 80, 56, 42), (37, 53, 28, 28), (64, 64, 64, 64),
-                                     (90, 120, 28, 56), (30, 40, 56, 70)])
-def test_oracle_resize_against_torch_interpolate(H, W, h, w):
-    """The reference's resize is torch's antialiased bicubic interpolate; torch's CPU kernel sums its taps in an unpublished
-    association, so the pin is: never more than ONE grey level apart, at most 1 pixel in 10 000 apart on noise and 3 in 1000 on a ramp full of exact ties."""
-    g = torch.Generator().manual_seed(H * 7 + w)
-    x = torch.randint(0, 256, (2, 3, H, W), generator=g, dtype=torch.uint8)
-    x[1] = (torch.arange(W).view(1, 1, W) * 255 // max(W - 1, 1) + torch.arange(H).view(1, H, 1)).clamp(0, 255).to(torch.uint8)   # smooth ramp
-    want = _torch_resize_u8(x, h, w)
-    got = R.resize_bicubic_aa_u8(x.numpy(), h, w)
-    d = np.abs(got.astype(int) - want.astype(int))
-    assert d.max() <= 1, f"oracle differs from torch by {d.max()} levels"
-    assert (d[0] != 0).mean() <= 1e-4, f"noise frame: {(d[0] != 0).sum()} of {d[0].size} pixels differ"
-    # the ramp interpolates to many EXACT .5 values, where the last bit of the fp32 sum decides the rounding
-    assert (d[1] != 0).mean() <= 3e-3, f"ramp frame: {(d[1] != 0).sum()} of {d[1].size} pixels differ"
-    if (H, W) == (h, w):
-        assert np.array_equal(got, x.numpy()), "same-size resize must be the identity"
+                                     (90, 120, 28, 56), (30, 40, 56, 70), (720, 1280, 252, 448)])
+def test_oracle_resize_equals_torch_interpolate_bit_for_bit(H, W, h, w):
+    """The reference's resize is torch's antialiased bicubic CPU kernel in float32.  The oracle restates that kernel's arithmetic
+    (formulas, double intermediates, FMA contraction, tap order: oracle/_c/resize_ref.c): the fp32 intermediate must be IDENTICAL
+    in every bit, hence the rounded uint8 too -- on noise and on a ramp whose values sit on exact .5 ties."""
+    x = resize_case_input(H, W, h, w)
+    t = _torch_f32(x, h, w)
     f = R.resize_bicubic_aa_f32(x.numpy(), h, w)
-    t = F.interpolate(x.float(), size=(h, w), mode="bicubic", antialias=True, align_corners=False).numpy()
-    assert np.abs(f - t).max() < 2e-3, "fp32 intermediate drifts from torch beyond summation-order noise"
+    assert np.array_equal(f.view(np.uint32), t.view(np.uint32)), f"{int((f.view(np.uint32) != t.view(np.uint32)).sum())} of {t.size} fp32 values differ from torch"
+    want = torch.from_numpy(t).clamp(0, 255).round().to(torch.uint8).numpy()
+    assert np.array_equal(R.resize_bicubic_aa_u8(x.numpy(), h, w), want)
+    if (H, W) == (h, w):
+        assert np.array_equal(want, x.numpy()), "same-size resize must be the identity"
+
+
+def test_oracle_resize_equals_the_committed_torch_outputs():
+    """The same pin without the installed torch's kernel in the loop: fp32 outputs and whole-axis tap weights (read off one-hot rows)
+    minted by oracle/make_golden.py --resize with the build container's torch."""
+    g = np.load(GOLD)
+    for (H, W, h, w) in RESIZE_CASES:
+        want = g[f"f32_{H}x{W}_{h}x{w}"]
+        got = R.resize_bicubic_aa_f32(resize_case_input(H, W, h, w).numpy(), h, w)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (H, W, h, w)
+    for (n_in, n_out) in RESIZE_AXES:
+        xmin, xsize, wt = R.aa_tables(n_in, n_out)
+        tab, lo = g[f"w_{n_in}_{n_out}"], g[f"lo_{n_in}_{n_out}"]
+        for i in range(n_out):            # torch's zero end taps cannot be told from padding in a probe: compare from the first non-zero one
+            k = int(lo[i] - xmin[i])
+            n = min(tab.shape[1], wt.shape[1] - k)
+            assert k >= 0 and np.array_equal(wt[i, k:k + n].view(np.uint32), tab[i, :n].view(np.uint32)), (n_in, n_out, i)
+            assert not wt[i, :k].any() and not wt[i, k + n:].any() and not tab[i, n:].any()
 
 
 @pytest.mark.parametrize("n_in,n_out", [(640, 448), (360, 252), (854, 448), (1280, 448), (720, 252), (320, 448), (240, 336), (448, 448),
