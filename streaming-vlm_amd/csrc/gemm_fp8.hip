@@ -83,6 +83,35 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned char* __re
   auto compute = [&](int stage) {
     const unsigned char* sa = smem + stage * STAGE_B;
     const unsigned char* sw = sa + BM * 128;
+#ifndef GEMM_FP8_NONSCALED
+    // One block-scaled MFMA per 128-deep K step: v_mfma_scale_f32_16x16x128_f8f6f4 with e4m3 operands runs at TWICE the bf16 rate
+    // (the non-scaled 16x16x32 fp8 form below: the bf16 rate, MI355X_MICROARCH.md "Matrix cores").  Block scales are all 2^0 (E8M0
+    // 127): the per-row x per-channel fp32 scales stay in the epilogue, so the arithmetic is the non-scaled kernel's -- exact fp8
+    // products, fp32 accumulation.  A dot product does not care in which order k is walked as long as both operands walk it alike:
+    // lane (fr, fq) takes the 16-byte chunks fq and 4 + fq of its row (two conflict-free ds_read_b128 of the swizzled image) as
+    // the 32 fp8 of its k block -- the four lane groups cover disjoint k ranges in both operands.
+    typedef int i8x_t __attribute__((ext_vector_type(8)));
+    typedef int i4x_t __attribute__((ext_vector_type(4)));
+    i8x_t af[TM], wf[4];
+    const int p0 = ((fq) ^ (fr & 7)) * 16, p1 = ((4 + fq) ^ (fr & 7)) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const unsigned char* r = sa + (wm * 16 * TM + i * 16 + fr) * 128;
+      const i4x_t lo = *reinterpret_cast<const i4x_t*>(r + p0), hi = *reinterpret_cast<const i4x_t*>(r + p1);
+      af[i] = i8x_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const unsigned char* r = sw + (wn * 64 + jj * 16 + fr) * 128;
+      const i4x_t lo = *reinterpret_cast<const i4x_t*>(r + p0), hi = *reinterpret_cast<const i4x_t*>(r + p1);
+      wf[jj] = i8x_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[jj], af[i], acc[i][jj], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+#else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       // A dot product does not care in which order k is walked as long as both operands walk it alike: lane (fr, fq) takes the
@@ -103,6 +132,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const unsigned char* __re
           for (int jj = 0; jj < 4; ++jj)
             acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wf[jj][h], af[i][h], acc[i][jj], 0, 0, 0);
     }
+#endif
   };
   constexpr int AHEAD = NS - 1;
 #pragma unroll
