@@ -339,15 +339,19 @@ def gen_full_size_vectors(which=("2b", "7b")):
              # window fills at chunk 14 and the last four chunks each evict (about an hour of host time)
              "7b_spec": ("cfg2_7b_448_2fps_win4096", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096,
                                                                         max_new=20, previous_text=""), 18),
-             # BASELINE configs[4] at the real 7B widths, mid-size: 32 chunks (64 frames, 8.8k prompt rows = three 4096-row prefill passes,
-             # four 8-grid ViT passes) piled into ONE forward, then 3 live chunks; the first live chunk compacts the cache to sink + window.
-             # Once with the bf16 tower, once with the fp8 tower recipe (oracle/model.py:linear_fp8; about an hour of host time each)
-             "7b_dense": ("cfg4_7b_dense32", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096, max_new=20,
-                                                                 previous_text="", dense_prefill_chunks=32), 35),
-             "7b_dense_fp8": ("cfg4_7b_dense32_fp8vit", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=4096, max_new=20,
-                                                                            previous_text="", dense_prefill_chunks=32), 35)}
+             # BASELINE configs[4] at the real 7B widths, mid-size: 10 chunks (20 frames, 2.8k prompt rows) piled into ONE forward, then 3
+             # live chunks; the first live chunk compacts the cache to sink + window (2048 here, so that it does).  The GPU replay runs
+             # the engine with PREFILL_ROWS = 1024 (three prefill passes) and its 8-grid ViT batching (8 + 2 grids).  Once with the bf16
+             # tower, once with the fp8 tower recipe (oracle/model.py:linear_fp8).  The full-size shape (300 chunks, 83k rows) costs the
+             # CPU oracle days (its attention materialises Hq x T x L scores); 32 chunks took 2 h 20 min and are not needed to run
+             # every mechanism.
+             "7b_dense": ("cfg4_7b_dense10", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=2048, max_new=20,
+                                                                 previous_text="", dense_prefill_chunks=10), 13),
+             "7b_dense_fp8": ("cfg4_7b_dense10_fp8vit", C.qwen2_vl_7b, dict(size=448, fps=2.0, policy="sink_window", sink=4, window=2048,
+                                                                            max_new=20, previous_text="", dense_prefill_chunks=10), 13)}
     for key in which:
         name, mk, kw, n = plans[key]
+        dense_chunks = kw.get("dense_prefill_chunks", 0)
         cfg = mk()
         sd = H.decisive_weights(cfg, size=kw["size"], max_new=kw["max_new"])
         from oracle import model as om
@@ -357,11 +361,14 @@ def gen_full_size_vectors(which=("2b", "7b")):
         finally:
             om.VIT_FP8 = False
         mm = min(H.greedy_margins(o))
-        assert mm >= 1.0, (name, mm)
+        # the streams' smallest top-2 margin is recorded and bounds the replay's logit tolerance (5 % of it); a dense prefill's first
+        # answered turn has no previous answer for the planted copy head to read, so its margins are the smallest (still > 5 x the bf16
+        # logit noise of the 7B, ~0.05)
+        assert mm >= (0.25 if dense_chunks else 1.0), (name, mm)
         tops = [[round(float(lg[t]), 4) for lg, t in zip(lgs, gen)] for lgs, gen in zip(o["logits"], o["generated"])]
         dense = kw.get("dense_prefill_chunks", 0)
         runs[name] = {"model": key.split("_")[0], "vit_fp8": key.endswith("_fp8"), "kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"],
-                      "top_logit": tops, "min_margin": round(mm, 4),
+                      "top_logit": tops, "min_margin": round(mm, 4), "prefill_rows": 1024 if dense else None,
                       "max_len": max(kw["sink"] + kw["window"] + 2 * 320 + 64, 64 + dense * 300 + 2 * 320),
                       "torch": torch.__version__}
         print(name, "min margin", mm, "kv_len", o["kv_len"])
@@ -377,7 +384,7 @@ if __name__ == "__main__":
         gen_resize_vectors()
         sys.exit(0)
     if "--full-only" in sys.argv:     # one full-size plan by key (2b / 7b / 7b_spec), nothing else re-minted
-        gen_full_size_vectors((sys.argv[sys.argv.index("--full-only") + 1],))
+        gen_full_size_vectors(tuple(sys.argv[sys.argv.index("--full-only") + 1].split(",")))
         sys.exit(0)
     gen_reference_vectors()
     gen_hf_vectors()

@@ -329,9 +329,12 @@ def test_evict_plan_kernel_edits_the_ids_like_the_host():
 def test_golden_full_size_streams_tokens_exact():
     """Full-size models against token streams minted by the CPU oracle in the build container (tests/golden/
     full_size_streams.json): BASELINE configs[1] -- Qwen2-VL-2B, 448x448 @1 fps, sink 4 / window 2048, 20 tokens per chunk,
-    12 chunks so that the window is full and evicts -- and configs[2]'s model at its frame rate (Qwen2-VL-7B, 448x448
-    @2 fps, window 512 so that 3 chunks evict).  Every eviction index and every greedy token must be identical; the logit
-    behind each token must sit within 5 % of the oracle's margin of the oracle's value."""
+    12 chunks so that the window is full and evicts --, configs[2]'s model at its frame rate (Qwen2-VL-7B, 448x448 @2 fps, window 512
+    so that 3 chunks evict), configs[2] AT SPEC (window 4096, 18 chunks: the window fills at chunk 14 and the last four evict) and
+    configs[4] at the 7B's widths, mid-size (10 chunks = 20 frames = 2.8k rows piled into one forward -- three prefill passes of
+    1024 rows, the ViT in passes of 8 + 2 grids --, then three live chunks, the first of which compacts the cache; bf16 and fp8
+    tower).  Every eviction index and every greedy token must be identical; the logit behind each token must sit within 5 % of
+    the oracle's margin of the oracle's value."""
     import json, os
     import streaming_vlm_amd as S
     from streaming_vlm_amd import config as C
@@ -343,6 +346,8 @@ def test_golden_full_size_streams_tokens_exact():
         sd = H.decisive_weights(cfg, size=kw["size"], max_new=kw["max_new"])
         model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=g["max_len"], max_new_tokens=kw["max_new"],
                                    vit_fp8=bool(g.get("vit_fp8", False)))
+        if g.get("prefill_rows") or "dense_prefill_chunks" in kw:       # mid-size dense prefill: several prefill passes over the 2.8k-row prompt
+            model._svlm_engine.PREFILL_ROWS = int(g.get("prefill_rows") or 1024)
         del sd
         _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], keep_logits=True, **kw)
         assert [[list(t) for t in c] for c in trace] == g["trace"], name
