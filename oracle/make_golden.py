@@ -360,15 +360,18 @@ def gen_full_size_vectors(which=("2b", "7b")):
             o = H.run_oracle_stream(cfg, sd, n, keep_logits=True, **kw)
         finally:
             om.VIT_FP8 = False
-        mm = min(H.greedy_margins(o))
-        # the streams' smallest top-2 margin is recorded and bounds the replay's logit tolerance (5 % of it); a dense prefill's first
-        # answered turn has no previous answer for the planted copy head to read, so its margins are the smallest (still > 5 x the bf16
-        # logit noise of the 7B, ~0.05)
-        assert mm >= (0.25 if dense_chunks else 1.0), (name, mm)
+        margins = H.greedy_margins(o)
+        mm = min(margins)
+        # Streams without a dense prefill: every step must be decisive (the replay runs free and requires every token).  A dense
+        # prefill's first answered turn has no previous answer for the planted copy head to read (it lands on header tokens or inside a
+        # vision span), so a few of its steps are near-ties: per-step margins are stored, the replay is teacher-forced with these
+        # tokens and requires the engine's own argmax wherever the oracle's margin is >= 1.
+        assert mm >= 1.0 or dense_chunks, (name, mm)
         tops = [[round(float(lg[t]), 4) for lg, t in zip(lgs, gen)] for lgs, gen in zip(o["logits"], o["generated"])]
         dense = kw.get("dense_prefill_chunks", 0)
         runs[name] = {"model": key.split("_")[0], "vit_fp8": key.endswith("_fp8"), "kwargs": kw, "n_chunks": n, "trace": o["trace"], "kv_len": o["kv_len"], "new_tokens": o["new_tokens"],
                       "top_logit": tops, "min_margin": round(mm, 4), "prefill_rows": 1024 if dense else None,
+                      "margins": [round(float(m), 4) for m in margins] if dense else None,
                       "max_len": max(kw["sink"] + kw["window"] + 2 * 320 + 64, 64 + dense * 300 + 2 * 320),
                       "torch": torch.__version__}
         print(name, "min margin", mm, "kv_len", o["kv_len"])
