@@ -114,6 +114,14 @@ int svlm_quant_rows_fp8(const void* x, int ldx, void* q, int ldq, float* scale, 
 int svlm_gemm_fp8(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
                   const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
                   const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream);
+/* svlm_gemm_fp8 whose fused norm ALSO leaves the normalised rows as the next GEMM's operand: XN8 (e4m3, rows of ldxn8 bytes) and
+ * xn_scale[M], exactly what svlm_quant_rows_fp8 would make of XN -- the quantiser launch between two Linears of the fp8 tower
+ * disappears (LayerNorm rows: inside the split-K reduce; RMSNorm rows: by the stand-alone quantiser behind it).
+ * replaces: the same Linears as svlm_gemm_fp8 (qwen2/vision_forward.py:43-49 in the fp8 configuration of BASELINE configs[4]). */
+int svlm_gemm_fp8_normq(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
+                        const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
+                        const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* XN8, int ldxn8, float* xn_scale,
+                        void* stream);
 
 /* In-place 2-D rope on the q and k parts of the fused ViT qkv buffer (N,3,H,d); cosT/sinT fp32 (N,d/2).
  * replaces: apply_rotary_pos_emb_vision (qwen2/vision_forward.py:27). */

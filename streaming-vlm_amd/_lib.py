@@ -30,6 +30,7 @@ SIGNATURES = {
     "svlm_gemm_bf16_norm": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _ll, _p, _p, _f, _p, _i, _p]),
     "svlm_quant_rows_fp8": (_i, [_p, _i, _p, _i, _p, _i, _i, _p]),
     "svlm_gemm_fp8": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _ll, _p, _p, _f, _p, _i, _p]),
+    "svlm_gemm_fp8_normq": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p, _ll, _p, _p, _f, _p, _i, _p, _i, _p, _p]),
     "svlm_gemv_bf16": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "svlm_prefetch": (_i, [_p, _ll, _i, _p]),
     "svlm_rmsnorm": (_i, [_p, _p, _p, _i, _i, _f, _p]),

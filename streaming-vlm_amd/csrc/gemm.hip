@@ -444,7 +444,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const floa
                                                                       const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
                                                                       bf16_t* C, int ldc, int M, int N, int act,
                                                                       const bf16_t* __restrict__ norm_w, const bf16_t* __restrict__ norm_b,
-                                                                      float eps, bf16_t* __restrict__ XN, int ldxn) {
+                                                                      float eps, bf16_t* __restrict__ XN, int ldxn,
+                                                                      unsigned char* __restrict__ XN8, int ldxn8, float* __restrict__ xn_scale) {
+  // XN8 != nullptr (fp8 ViT tower): the normalised row also leaves as e4m3 + one fp32 scale per row, the recipe of
+  // quant_rows_fp8_kernel (gemm_fp8.hip) applied to the bf16 values XN holds -- the next GEMM's operand without a quantiser launch.
   // one workgroup per row, 8 columns per thread and pass: all slab loads of a thread are independent and issued together.
   // norm_b == nullptr: RMSNorm (Qwen2RMSNorm); else LayerNorm with bias (the ViT's norm1 / norm2, one rounding at the end).
   const int m = blockIdx.x, tid = threadIdx.x;
@@ -518,7 +521,40 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const floa
         unpack8(*reinterpret_cast<const u32x4_t*>(norm_b + n), h);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = (y[it][i] - mean) * rstd * g[i] + h[i];
-        *reinterpret_cast<u32x4_t*>(XN + (size_t)m * ldxn + n) = pack8(f);
+        const u32x4_t o = pack8(f);
+        *reinterpret_cast<u32x4_t*>(XN + (size_t)m * ldxn + n) = o;
+        unpack8(o, y[it]);                                 // keep the bf16 values for the quantiser below
+      }
+    }
+    if (XN8 != nullptr) {
+      __shared__ float redm[4];
+      float mx = 0.f;
+#pragma unroll
+      for (int it = 0; it < RN_IT; ++it)
+        if (it * 2048 + tid * 8 < N) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(y[it][i]));
+        }
+      mx = wave_max(mx);
+      if ((tid & 63) == 0) redm[tid >> 6] = mx;
+      __syncthreads();
+      mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+      const float sc = mx > 0.f ? mx / 448.0f : 1.0f;
+      if (tid == 0) xn_scale[m] = sc;
+#pragma unroll
+      for (int it = 0; it < RN_IT; ++it) {
+        const int n = it * 2048 + tid * 8;
+        if (n < N) {
+          u32x2_t o;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(y[it][4 * hh] / sc, y[it][4 * hh + 1] / sc, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(y[it][4 * hh + 2] / sc, y[it][4 * hh + 3] / sc, w, true);
+            o[hh] = (unsigned)w;
+          }
+          *reinterpret_cast<u32x2_t*>(XN8 + (size_t)m * ldxn8 + n) = o;
+        }
       }
     }
     return;
@@ -541,13 +577,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_norm_kernel(const floa
 }
 
 extern "C" int svlm_rmsnorm(const void* x, const void* w, void* y, int rows, int cols, float eps, void* stream);
+extern "C" int svlm_quant_rows_fp8(const void* x, int ldx, void* q, int ldq, float* scale, int rows, int cols, void* stream);
 extern "C" int svlm_layernorm(const void* x, const void* w, const void* b, void* y, int rows, int cols, float eps, void* stream);
 
 static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                      void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream,
                      const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn);
 int svlm_gemm_reduce_launch(const float* partial, int splits, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
-                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream);
+                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream, void* XN8 = nullptr,
+                            int ldxn8 = 0, float* xn_scale = nullptr);
 
 extern "C" int svlm_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                               void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes, void* stream) {
@@ -794,13 +832,17 @@ static int gemm_impl(const void* A, int lda, const void* W, int ldw, const void*
 
 // Tail shared by the bf16 and fp8 GEMMs: split-K reduce (+ epilogue), with the norm of the output row folded in when there is one.
 int svlm_gemm_reduce_launch(const float* partial, int splits, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
-                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream) {
+                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream, void* XN8, int ldxn8,
+                            float* xn_scale) {
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (splits > 1 && norm_w != nullptr && N <= 2048 * RN_IT) {      // reduce + RMSNorm of the reduced row in one launch
     gemm_splitk_reduce_norm_kernel<<<M, 256, 0, st>>>(partial, splits, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)C,
-                                                                ldc, M, N, act, (const bf16_t*)norm_w, (const bf16_t*)norm_b, eps, (bf16_t*)XN, ldxn);
-    return svlm_check_launch("svlm_gemm_bf16_norm(split-K reduce + norm)");
+                                                                ldc, M, N, act, (const bf16_t*)norm_w, (const bf16_t*)norm_b, eps, (bf16_t*)XN, ldxn,
+                                                                norm_b ? (unsigned char*)XN8 : nullptr, ldxn8, xn_scale);
+    rc = svlm_check_launch("svlm_gemm_bf16_norm(split-K reduce + norm)");
+    if (rc || XN8 == nullptr || norm_b != nullptr) return rc;
+    return svlm_quant_rows_fp8(XN, ldxn, XN8, ldxn8, xn_scale, M, N, stream);          // RMSNorm rows: quantised by the stand-alone kernel
   }
   if (splits > 1) {
     const size_t total = (size_t)M * (N / 4);
@@ -812,5 +854,7 @@ int svlm_gemm_reduce_launch(const float* partial, int splits, const void* bias, 
   }
   if (norm_w == nullptr) return SVLM_OK;
   SVLM_CHECK_ARG(ldc == N && ldxn == N, "svlm_gemm_bf16_norm: the unfused norm needs contiguous rows (ldc=%d ldxn=%d N=%d)", ldc, ldxn, N);
-  return norm_b ? svlm_layernorm(C, norm_w, norm_b, XN, M, N, eps, stream) : svlm_rmsnorm(C, norm_w, XN, M, N, eps, stream);
+  rc = norm_b ? svlm_layernorm(C, norm_w, norm_b, XN, M, N, eps, stream) : svlm_rmsnorm(C, norm_w, XN, M, N, eps, stream);
+  if (rc || XN8 == nullptr) return rc;
+  return svlm_quant_rows_fp8(XN, ldxn, XN8, ldxn8, xn_scale, M, N, stream);
 }

@@ -225,11 +225,35 @@ extern "C" int svlm_quant_rows_fp8(const void* x, int ldx, void* q, int ldq, flo
 
 // split-K reduce kernels of gemm.hip (the fp8 kernel writes SCALED fp32 partials, so the bf16 reduce epilogues apply as they are)
 int svlm_gemm_reduce_launch(const float* partial, int splits, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
-                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream);
+                            int act, const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream, void* XN8 = nullptr,
+                            int ldxn8 = 0, float* xn_scale = nullptr);
+
+static int gemm_fp8_impl(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
+                         const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
+                         const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* XN8, int ldxn8, float* xn_scale, void* stream);
 
 extern "C" int svlm_gemm_fp8(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
                              const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
                              const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* stream) {
+  return gemm_fp8_impl(A8, lda, a_scale, W8, ldw, w_scale, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, norm_w, norm_b, eps, XN, ldxn,
+                       nullptr, 0, nullptr, stream);
+}
+
+// svlm_gemm_fp8 whose fused norm ALSO leaves the normalised rows as the next GEMM's fp8 operand (e4m3 + one fp32 scale per row, the
+// recipe of svlm_quant_rows_fp8 on the bf16 values of XN): the quantiser launch between two Linears of the fp8 tower disappears.
+extern "C" int svlm_gemm_fp8_normq(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
+                                   const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
+                                   const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* XN8, int ldxn8, float* xn_scale,
+                                   void* stream) {
+  SVLM_CHECK_ARG(norm_w != nullptr && XN != nullptr && XN8 != nullptr && xn_scale != nullptr && ldxn8 % 8 == 0 && ldxn8 >= N,
+                 "svlm_gemm_fp8_normq: needs a norm, its bf16 output, an fp8 output with 8-B aligned rows and a scale vector (ldxn8=%d N=%d)", ldxn8, N);
+  return gemm_fp8_impl(A8, lda, a_scale, W8, ldw, w_scale, bias, residual, ldr, C, ldc, M, N, K, act, ws, ws_bytes, norm_w, norm_b, eps, XN, ldxn,
+                       XN8, ldxn8, xn_scale, stream);
+}
+
+static int gemm_fp8_impl(const void* A8, int lda, const float* a_scale, const void* W8, int ldw, const float* w_scale, const void* bias,
+                         const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* ws, long long ws_bytes,
+                         const void* norm_w, const void* norm_b, float eps, void* XN, int ldxn, void* XN8, int ldxn8, float* xn_scale, void* stream) {
   SVLM_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % F8_BK == 0 && N % 4 == 0, "svlm_gemm_fp8: bad shape M=%d N=%d K=%d (K %% 128 == 0, N %% 4 == 0)", M, N, K);
   SVLM_CHECK_ARG(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldc % 4 == 0 && ldc >= N && (!residual || ldr % 4 == 0),
                  "svlm_gemm_fp8: leading dims must keep 16-B row alignment (lda=%d ldw=%d ldc=%d ldr=%d)", lda, ldw, ldc, ldr);
@@ -283,6 +307,6 @@ extern "C" int svlm_gemm_fp8(const void* A8, int lda, const float* a_scale, cons
   int rc = svlm_check_launch("svlm_gemm_fp8");
   if (rc) return rc;
   if (splits > 1 || norm_w != nullptr)
-    return svlm_gemm_reduce_launch(partial, splits, bias, residual, ldr, C, ldc, M, N, act, norm_w, norm_b, eps, XN, ldxn, stream);
+    return svlm_gemm_reduce_launch(partial, splits, bias, residual, ldr, C, ldc, M, N, act, norm_w, norm_b, eps, XN, ldxn, stream, XN8, ldxn8, xn_scale);
   return SVLM_OK;
 }

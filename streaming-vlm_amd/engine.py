@@ -134,24 +134,32 @@ class _VitRun:
         x, h, qkv, a, f = self.x, self.h, self.qkv, self.a, self.f
         blocks = self.eng.w.vit
         w8 = self.eng.vit_w8
+        # The two LayerNorm outputs of a block leave their producer (the split-K reduce of proj / fc2) already quantised: e4m3 + row
+        # scales beside the bf16 row (svlm_gemm_fp8_normq), so only the attention output and the GELU output still go through the
+        # stand-alone quantiser.  `_hq_ready`: q_e / s_row hold the quantised norm1 row of the next block.
         if lo < hi and not self._h_is_norm1:
             o.layernorm(x, blocks[lo]["n1w"], blocks[lo]["n1b"], 1e-6, out=h)
+            self._hq_ready = False
         for bi in range(lo, hi):
             bw, b8 = blocks[bi], w8[bi]
-            o.quant_rows_fp8(h, self.q_e, self.s_row)
+            if not getattr(self, "_hq_ready", False):
+                o.quant_rows_fp8(h, self.q_e, self.s_row)
             o.gemm_fp8(self.q_e, self.s_row, *b8["qkv"], bias=bw["qkv_b"], out=qkv)
             o.vit_rope(qkv, self.cosT, self.sinT, Hh, d)
             o.vit_attn(qkv, self.n_seq, self.seq_len, Hh, d, scale, out=a)
             o.quant_rows_fp8(a, self.q_e, self.s_row)
-            o.gemm_fp8(self.q_e, self.s_row, *b8["proj"], bias=bw["proj_b"], residual=x, out=x, norm_w=bw["n2w"], norm_b=bw["n2b"], out_norm=h)
-            o.quant_rows_fp8(h, self.q_e, self.s_row)
+            o.gemm_fp8(self.q_e, self.s_row, *b8["proj"], bias=bw["proj_b"], residual=x, out=x, norm_w=bw["n2w"], norm_b=bw["n2b"], out_norm=h,
+                       out_norm_q=(self.q_e, self.s_row))
             o.gemm_fp8(self.q_e, self.s_row, *b8["fc1"], bias=bw["fc1_b"], out=f, act=ACT_QUICK_GELU)
             o.quant_rows_fp8(f, self.q_f, self.s_row)
             if bi + 1 < len(blocks):
                 nb = blocks[bi + 1]
-                o.gemm_fp8(self.q_f, self.s_row, *b8["fc2"], bias=bw["fc2_b"], residual=x, out=x, norm_w=nb["n1w"], norm_b=nb["n1b"], out_norm=h)
+                o.gemm_fp8(self.q_f, self.s_row, *b8["fc2"], bias=bw["fc2_b"], residual=x, out=x, norm_w=nb["n1w"], norm_b=nb["n1b"], out_norm=h,
+                           out_norm_q=(self.q_e, self.s_row))
+                self._hq_ready = True
             else:
                 o.gemm_fp8(self.q_f, self.s_row, *b8["fc2"], bias=bw["fc2_b"], residual=x, out=x)
+                self._hq_ready = False
         if lo < hi:
             self._h_is_norm1 = hi < len(blocks)
 

@@ -144,8 +144,9 @@ class HipOps:
         return q, scale
 
     def gemm_fp8(self, A8, a_scale, W8, w_scale, bias=None, residual=None, out=None, act=ACT_NONE, norm_w=None, norm_b=None, eps=1e-6,
-                 out_norm=None):
-        """out = epi((A8 @ W8^T) * a_scale[:, None] * w_scale[None, :]); with norm_w: out_norm = norm(out) as `gemm_norm`."""
+                 out_norm=None, out_norm_q=None):
+        """out = epi((A8 @ W8^T) * a_scale[:, None] * w_scale[None, :]); with norm_w: out_norm = norm(out) as `gemm_norm`;
+        `out_norm_q` = (fp8 tensor, fp32 row scales): out_norm quantised for the next fp8 GEMM inside the same call."""
         _req(A8, self.FP8, "gemm_fp8.A", 2); _req(W8, self.FP8, "gemm_fp8.W", 2)
         _req(a_scale, torch.float32, "gemm_fp8.a_scale", 1); _req(w_scale, torch.float32, "gemm_fp8.w_scale", 1)
         M, K = A8.shape
@@ -168,6 +169,14 @@ class HipOps:
             assert norm_w.numel() == N and tuple(out_norm.shape) == (M, N)
             ldxn = out_norm.stride(0)
         ws = self._ws(A8.device)
+        if out_norm_q is not None:
+            q8, qs = out_norm_q
+            _req(q8, self.FP8, "gemm_fp8.out_norm_q", 2); _req(qs, torch.float32, "gemm_fp8.out_norm_scale", 1)
+            assert norm_w is not None and tuple(q8.shape) == (M, N) and qs.numel() == M
+            check(self.lib.svlm_gemm_fp8_normq(_ptr(A8), A8.stride(0), _ptr(a_scale), _ptr(W8), W8.stride(0), _ptr(w_scale), _ptr(bias), _ptr(residual),
+                                               ldr, _ptr(out), out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _ptr(norm_w), _ptr(norm_b),
+                                               float(eps), _ptr(out_norm), ldxn, _ptr(q8), q8.stride(0), _ptr(qs), _stream()), "svlm_gemm_fp8_normq")
+            return out
         check(self.lib.svlm_gemm_fp8(_ptr(A8), A8.stride(0), _ptr(a_scale), _ptr(W8), W8.stride(0), _ptr(w_scale), _ptr(bias), _ptr(residual), ldr,
                                      _ptr(out), out.stride(0), M, N, K, act, _ptr(ws), ws.numel() * 4, _ptr(norm_w), _ptr(norm_b), float(eps),
                                      _ptr(out_norm), ldxn, _stream()), "svlm_gemm_fp8")

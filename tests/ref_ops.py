@@ -204,7 +204,8 @@ class RefOps:
             return q, scale
         return qv, s
 
-    def gemm_fp8(self, A8, a_scale, W8, w_scale, bias=None, residual=None, out=None, act=0, norm_w=None, norm_b=None, eps=1e-6, out_norm=None):
+    def gemm_fp8(self, A8, a_scale, W8, w_scale, bias=None, residual=None, out=None, act=0, norm_w=None, norm_b=None, eps=1e-6, out_norm=None,
+                 out_norm_q=None):
         y = (A8.float() @ W8.float().t()) * (a_scale.reshape(-1, 1) * w_scale.reshape(1, -1))
         if bias is not None:
             y = y + bias.float()
@@ -219,6 +220,8 @@ class RefOps:
                 out_norm.copy_(F.layer_norm(out, (out.shape[-1],), norm_w, norm_b, eps))
             else:
                 out_norm.copy_(om.rms_norm(out, norm_w, eps))
+            if out_norm_q is not None:
+                self.quant_rows_fp8(out_norm, out_norm_q[0], out_norm_q[1])
         return out
 
     def mark_seen(self, ids, n, seen):

@@ -743,6 +743,18 @@ def test_gemm_fp8_fused_norm(ops, ref):
     ref.gemm_fp8(a8.cpu(), sa.cpu(), w8.cpu(), sw.cpu(), bias=b, residual=R, out=o2, norm_w=nw.to(BF16), norm_b=nb.to(BF16), out_norm=n2)
     close("gemm_fp8+LN out", out, o2)
     close("gemm_fp8+LN norm", outn, n2, max_tol=2 ** -6)
+    # the same call with the normalised rows leaving as the next GEMM's fp8 operand: IDENTICAL bf16 outputs, and codes + scales equal to
+    # what the stand-alone quantiser makes of the kernel's own normalised rows (LayerNorm rows inside the reduce; RMSNorm rows behind it)
+    for nbias in (nb.to(BF16).cuda(), None):
+        out3, outn3 = torch.empty_like(out), torch.empty_like(outn)
+        q8 = torch.empty((M, N), dtype=torch.float8_e4m3fn, device="cuda")
+        qs = torch.empty((M,), dtype=torch.float32, device="cuda")
+        ops.gemm_fp8(a8, sa, w8, sw, bias=b.cuda(), residual=R.cuda(), out=out3, norm_w=nw.to(BF16).cuda(), norm_b=nbias, out_norm=outn3,
+                     out_norm_q=(q8, qs))
+        if nbias is not None:
+            assert torch.equal(out3, out) and torch.equal(outn3, outn)
+        wq, ws_ = ops.quant_rows_fp8(outn3)
+        assert torch.equal(qs, ws_) and torch.equal(q8.view(torch.uint8), wq.view(torch.uint8)), "fused quantisation differs from svlm_quant_rows_fp8"
 
 
 def test_vit_tower_fp8_vs_oracle_fp8_and_bf16():
