@@ -353,7 +353,8 @@ def test_golden_full_size_streams_tokens_exact():
         # a stream minted with per-step margins (the dense prefill: a few near-ties in its first answered turn) is replayed
         # teacher-forced with the oracle's tokens, so that a near-tie cannot send the rest of the stream elsewhere; the engine's OWN
         # argmax is what is compared
-        force = g["new_tokens"] if margins else None
+        # ("new_tokens" carries the <|im_end|> the loop appends behind a turn that ran to max_new_tokens; the generated ones come first)
+        force = [c[:kw["max_new"]] for c in g["new_tokens"]] if margins else None
         _, trace, counts, ids_log = H.run_engine_stream(model, g["n_chunks"], keep_logits=True, force_tokens=force, **kw)
         assert [[list(t) for t in c] for c in trace] == g["trace"], name
         assert [e["kv_len"] for e in ids_log] == g["kv_len"], name
@@ -365,7 +366,7 @@ def test_golden_full_size_streams_tokens_exact():
                 worst = max(worst, abs(float(lg[tok]) - top))
         if margins:
             flat_got = [t for c in got for t in c]
-            flat_want = [t for c in g["new_tokens"] for t in c]
+            flat_want = [t for c in force for t in c]
             assert len(flat_got) == len(flat_want) == len(margins), name
             decisive = [m for m in margins if m >= 1.0]
             n_dec = sum(int(a == b) for a, b, m in zip(flat_got, flat_want, margins) if m >= 1.0)
