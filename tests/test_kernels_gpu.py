@@ -757,17 +757,19 @@ def test_gemm_fp8_fused_norm(ops, ref):
         assert torch.equal(qs, ws_) and torch.equal(q8.view(torch.uint8), wq.view(torch.uint8)), "fused quantisation differs from svlm_quant_rows_fp8"
 
 
-def test_vit_tower_fp8_vs_oracle_fp8_and_bf16():
+@pytest.mark.parametrize("depth", [1, 4])
+def test_vit_tower_fp8_vs_oracle_fp8_and_bf16(depth):
     """The Qwen2-VL vision tower at its REAL widths (1280 / 16 heads of 80 / 5120, merger 5120 -> 1536; 4 blocks keep the CPU oracle
     short) on the fp8 path: HIP vs the oracle with the same fp8 recipe (tight), and the recipe vs the bf16 tower (the price of fp8,
-    reported; the reference has no fp8 path, so against the reference this configuration is parity-unpinned)."""
+    reported; the reference has no fp8 path, so against the reference this configuration is parity-unpinned).  depth = 1 is the
+    PER-BLOCK bar: one block (four fp8 Linears, two of them quantised inside the split-K reduce) + the merger."""
     import streaming_vlm_amd as S
     from streaming_vlm_amd import config as C
     from streaming_vlm_amd.weights import random_state_dict
     from oracle import model as om
     import helpers as H
     cfg = C.qwen2_vl_2b()
-    cfg.vision.depth, cfg.text.num_layers = 4, 1
+    cfg.vision.depth, cfg.text.num_layers = depth, 1
     sd = random_state_dict(cfg, 0, "cpu")
     eng = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=512, max_new_tokens=4, vit_fp8=True)._svlm_engine
     pix, grid = S.patchify(torch.stack([S.synthetic_frame(0, t, 448) for t in range(2)]))
@@ -783,7 +785,7 @@ def test_vit_tower_fp8_vs_oracle_fp8_and_bf16():
     e_hip = float((got - want8).abs().mean()) / sc
     e_fmt = float((want8 - want16).abs().mean()) / sc
     e_hip16 = float((got - want16).abs().mean()) / sc
-    print(f"[vit fp8] HIP vs fp8 oracle: mean|d|/max = {e_hip:.3e}; fp8 oracle vs bf16 tower: {e_fmt:.3e}; HIP vs bf16 tower: {e_hip16:.3e}")
+    print(f"[vit fp8 depth {depth}] HIP vs fp8 oracle: mean|d|/max = {e_hip:.3e}; fp8 oracle vs bf16 tower: {e_fmt:.3e}; HIP vs bf16 tower: {e_hip16:.3e}")
     # Per GEMM the two agree to bf16 flips (test_gemm_fp8).  Through a tower they cannot stay that close: a one-ulp bf16 flip in a
     # GEMM input that sits on an e4m3 rounding boundary moves that element by a whole fp8 step (6 %), so any two valid orderings
     # of the fp32 sums drift apart by a share of the quantisation noise itself.  The bars: the HIP tower is no further from the
