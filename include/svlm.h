@@ -225,23 +225,27 @@ int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int 
 int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, const void* W, int ldw, void* h, int I, int K, void* stream);
 
 /* ---- persistent decode-layer tail: o_proj + residual -> RMSNorm -> gate/up + SwiGLU -> down_proj + residual -> (next layer's)
- * RMSNorm -> QKV + bias + KV append, as ONE launch of one 4-wave workgroup per CU (csrc/dec_tail.hip).  The four all-to-all seams
- * inside it are 8-byte {tag, 2 x bf16} granule hand-offs swept by one gatherer wave per workgroup; the weight stream runs ahead of
- * every seam through a ring of register batches.  Same arithmetic and rounding points as svlm_gemv_bf16 (o_proj, down_proj),
- * svlm_dec_gate_up and svlm_dec_qkv, which it replaces inside a decode step.
+ * RMSNorm -> QKV + bias + KV append, as ONE launch of one 16-wave workgroup per CU (csrc/dec_tail.hip).  Every consumer wave requests
+ * ALL its gate/up and down_proj rows in its first microsecond (the whole layer's tail, 93.6 MB on Qwen2-VL-2B, is in flight in the
+ * register files at once), so HBM streams the layer without a pause while the three all-to-all seams inside the launch -- 8-byte
+ * {tag, 2 x bf16} granule hand-offs swept by one gatherer wave per workgroup -- go by.  Same rounding points as svlm_gemv_bf16
+ * (o_proj, down_proj), svlm_dec_gate_up and svlm_dec_qkv, which it replaces inside a decode step.
  * replaces: the per-layer module calls of qwen2/language_forward.py:161 (o_proj), :196-202 (residual, post_attention_layernorm, Qwen2MLP,
  * residual) and the next layer's :183,80-82 (input_layernorm, q/k/v_proj) + generate/streaming_cache.py:72-73 (cache append), i.e.
  * the body of the per-layer loop at :278 between two attention calls.
+ *   svlm_dec_tail_supported: 1 when the layer geometry has a build at `grid` workgroups (its weights must fit the register file:
+ *       Qwen2-VL-2B class and small test widths), 0 otherwise (use the per-op entry points); host arithmetic.
  *   ws: svlm_dec_tail_ws_bytes(H, I, n_layers) bytes = [256-B status block][one granule block per layer]; int status = ((int*)ws)[0] is
  *       sticky: non-zero once any gatherer gave up its (bounded) spin -- results of that step are then invalid; the caller checks it once
  *       per chunk and clears it.  svlm_dec_tail_reset zeroes the granule blocks (NOT the status) and must run once before the tails of
  *       every decode step (a memset node at the head of the step's graph).
  *   attn [qd], x [H] (in: residual stream, out: the layer's output), weights as in the per-op entry points.
  *   ln1_next == NULL: last layer, no QKV phase (q_out / planes / slot_of unused).
- *   grid: workgroups to launch, 0 = one per CU.  All of them must be able to become resident together (one 256-thread workgroup of
- *       <= 256 VGPRs per CU always can); results do not depend on where they land.
+ *   grid: workgroups to launch, 0 = one per CU; never more than the device has CUs (every workgroup waits for every other one's
+ *       outputs, so all must be resident together); results do not depend on where they land.
  *   stamps: NULL, or [grid][2][16] uint64 wall-clock stamps of the gatherer's and the first consumer's barrier passes (a profiling aid of
  *       tools/dec_tail_bench.py). */
+int svlm_dec_tail_supported(int H, int I, int qd, int kd, int grid); /* [host] */
 long long svlm_dec_tail_ws_bytes(int H, int I, int n_layers); /* [host] */
 int svlm_dec_tail_reset(void* ws, int H, int I, int n_layers, void* stream);
 int svlm_dec_tail(const void* attn, void* x, const void* o_w, int ld_o, const void* ln2, const void* gu_w, int ld_gu, const void* down_w,

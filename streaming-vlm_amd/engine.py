@@ -323,6 +323,9 @@ class SvlmEngine:
         if self.decode_tail:
             if not hasattr(ops, "dec_tail"):
                 raise ValueError("decode_tail=True needs an ops backend with dec_tail (the HIP library)")
+            if hasattr(ops, "dec_tail_supported") and not ops.dec_tail_supported(H, tc.intermediate_size, self.qd, self.kd):
+                raise ValueError(f"decode_tail=True: no build of the persistent layer tail for hidden {H} / intermediate {tc.intermediate_size} "
+                                 "(a layer's weights must fit the register files: Qwen2-VL-2B class); use the per-op decode step")
             self.tail_ws = ops.dec_tail_ws(H, tc.intermediate_size, len(self.w.layers), dev)
             self._tail_status_host = torch.zeros(1, dtype=torch.int64).pin_memory() if dev.type == "cuda" else None
         self._vit_rope_cache = {}

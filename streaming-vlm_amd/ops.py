@@ -531,6 +531,12 @@ class HipOps:
         check(self.lib.svlm_dec_gate_up(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(h), N // 2, K, _stream()), "svlm_dec_gate_up")
 
     # ---- persistent decode-layer tail (csrc/dec_tail.hip)
+    def dec_tail_supported(self, H, I, qd, kd, grid=0):
+        """True when svlm_dec_tail has a build for this layer geometry (its weights must fit the CUs' register files)."""
+        if not grid:
+            grid = self.lib.svlm_device_cus()
+        return self.lib.svlm_dec_tail_supported(int(H), int(I), int(qd), int(kd), int(grid)) == 1
+
     def dec_tail_ws(self, H, I, n_layers, device):
         """Granule workspace of a decode step's tails: [256-B status block | one granule block per layer], zero-initialised."""
         n = self.lib.svlm_dec_tail_ws_bytes(int(H), int(I), int(n_layers))

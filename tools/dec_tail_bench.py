@@ -34,6 +34,7 @@ def per_op():
         ops.dec_qkv(x, L["ln1"], tc.rms_eps, L["qkv"], L["b"], q, pool, i + 1, slot, qd, kd, len_dev=ln)
 
 
+assert ops.dec_tail_supported(H, I, qd, kd), "no svlm_dec_tail build for this model (2B class only)"
 stamps = torch.zeros((256, 2, 16), dtype=torch.int64, device=dev)
 STAMP_LAYER = nl // 2
 
@@ -75,8 +76,8 @@ print(json.dumps({"model": which, "layers": nl, "MB_per_layer": round(mb, 1), "p
 if "stamps" in sys.argv:
     st = stamps.cpu().numpy().astype("float64")
     t0 = st[:, :, 0].min()
-    names_g = ["start", "B0", "x1 gathered", "B1", "h gathered", "B2", "B3", "x2 gathered", "B4"]
-    names_c = ["start", "B0 arrive", "B0", "B1 arrive", "B1", "B2 arrive", "B2", "B3 arrive", "B3", "B4 arrive", "B4", "end"]
+    names_g = ["start", "x1 published", "x1 gathered", "B1", "h gathered", "B2", "B3", "x2 gathered", "B4"]
+    names_c = ["start", "loads issued", "B1", "GU done", "h published", "B2", "DOWN done", "x2 published", "B4", "end"]
     import numpy as np
     for role, names in ((0, names_g), (1, names_c)):
         for i, n in enumerate(names):
