@@ -316,7 +316,7 @@ class SvlmEngine:
         self.d_ws = ops.decode_attn_ws(tc.num_heads, self.max_len, 16 if self._fixed_chunk is None else self.decode_chunk, dev)
         self.d_sws = ops.sampling_ws(V, dev)
         # decode-step structure: per-op launches (6 per layer), or the persistent layer tail (csrc/dec_tail.hip: o_proj -> gate/up ->
-        # down_proj -> next layer's QKV in ONE launch per layer, 3 launches per layer with the attention pair).  Measured slower than
+        # down_proj -> next layer's QKV in ONE launch per layer, 3 launches per layer with the attention pair; 2B-class layers).  Measured slower than
         # the per-op launches on MI355X (profiles/r03_dec_tail_*.json), so it is opt-in.
         self.decode_tail = (os.environ.get("SVLM_DECODE_TAIL", "0") == "1") if decode_tail is None else bool(decode_tail)
         self.tail_ws = None
