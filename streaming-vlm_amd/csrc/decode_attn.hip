@@ -415,7 +415,7 @@ struct DaTile {
   u32x4_t k[4], cs[4], v[4];     // K pieces ks = 0..3; cos pieces 0,1 and sin pieces 0,1; V rows 4 i + (lane >> 4), chunk lane & 15
 };
 
-template <int G>
+template <int G, int DIAG = 0>       // DIAG (diagnostic build only): 1 = no cos/sin loads, no rotation; 2 = loads only, no arithmetic at all
 __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
     const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
@@ -477,10 +477,12 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     const bf16_t* csr = rope_cs + (size_t)lrow * DA_D + fq * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b.k[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(krow + ks * 32));
-    b.cs[0] = *reinterpret_cast<const u32x4_t*>(csr);
-    b.cs[1] = *reinterpret_cast<const u32x4_t*>(csr + 32);
-    b.cs[2] = *reinterpret_cast<const u32x4_t*>(csr + 64);
-    b.cs[3] = *reinterpret_cast<const u32x4_t*>(csr + 96);
+    if constexpr ((DIAG & 1) == 0) {
+      b.cs[0] = *reinterpret_cast<const u32x4_t*>(csr);
+      b.cs[1] = *reinterpret_cast<const u32x4_t*>(csr + 32);
+      b.cs[2] = *reinterpret_cast<const u32x4_t*>(csr + 64);
+      b.cs[3] = *reinterpret_cast<const u32x4_t*>(csr + 96);
+    }
     // V rows for the slab: row 4 i + fq, 16-B chunk fr; that row's slot sits in lane 4 i + fq
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -496,20 +498,37 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
 
   auto compute = [&](int t, const DaTile& b) {
     const int base = (t * 4 + wave) * 16;                   // first key of the tile, relative to `start`
+    if constexpr ((DIAG & 2) != 0) {                        // timing only: every loaded register is consumed, nothing else happens
+      unsigned x = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x ^= b.k[i][0] ^ b.k[i][1] ^ b.k[i][2] ^ b.k[i][3] ^ b.v[i][0] ^ b.v[i][1] ^ b.v[i][2] ^ b.v[i][3];
+      if constexpr ((DIAG & 1) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x ^= b.cs[i][0] ^ b.cs[i][1] ^ b.cs[i][2] ^ b.cs[i][3];
+      }
+      oacc[0][0] += __uint_as_float(x & 0x3F800000u);
+      l_w = 1.f; m_w = 0.f;
+      return;
+    }
     // ---- RoPE on registers: out(d) = bf(bf(x c) + bf(rot s)), rot = -x(d + 64) for d < 64, x(d - 64) above
     bf16x8_t kf[4];
+    if constexpr ((DIAG & 1) != 0) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float xl[8], xu[8], cc[8], sn[8], ol[8], ou[8];
-      unpack8(b.k[h], xl); unpack8(b.k[h + 2], xu); unpack8(b.cs[h], cc); unpack8(b.cs[2 + h], sn);
+      for (int h = 0; h < 4; ++h) { u32x4_t kk = b.k[h]; kf[h] = *reinterpret_cast<bf16x8_t*>(&kk); }
+    } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        ol[i] = rbf(rbf(xl[i] * cc[i]) + rbf(-xu[i] * sn[i]));
-        ou[i] = rbf(rbf(xu[i] * cc[i]) + rbf(xl[i] * sn[i]));
+      for (int h = 0; h < 2; ++h) {
+        float xl[8], xu[8], cc[8], sn[8], ol[8], ou[8];
+        unpack8(b.k[h], xl); unpack8(b.k[h + 2], xu); unpack8(b.cs[h], cc); unpack8(b.cs[2 + h], sn);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          ol[i] = rbf(rbf(xl[i] * cc[i]) + rbf(-xu[i] * sn[i]));
+          ou[i] = rbf(rbf(xu[i] * cc[i]) + rbf(xl[i] * sn[i]));
+        }
+        u32x4_t pl = pack8(ol), pu = pack8(ou);
+        kf[h] = *reinterpret_cast<bf16x8_t*>(&pl);
+        kf[h + 2] = *reinterpret_cast<bf16x8_t*>(&pu);
       }
-      u32x4_t pl = pack8(ol), pu = pack8(ou);
-      kf[h] = *reinterpret_cast<bf16x8_t*>(&pl);
-      kf[h + 2] = *reinterpret_cast<bf16x8_t*>(&pu);
     }
     // ---- V to the wave's slab (LDS operations of one wave are executed in order: no barrier)
 #pragma unroll
@@ -708,7 +727,7 @@ static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_
   // diagnostic build only: the multi-pass long-cache kernel the streaming kernel replaced, and its timing-only DIAG variants
   static const int diag = svlm_env("SVLM_DA_DIAG") ? atoi(svlm_env("SVLM_DA_DIAG")) : 0;
   static const bool stream_k = svlm_env("SVLM_DA_STREAM") == nullptr || atoi(svlm_env("SVLM_DA_STREAM")) != 0;
-  if (chunk > 16 * DA_MAX_STEPS && !(stream_k && diag == 0)) {
+  if (chunk > 16 * DA_MAX_STEPS && !stream_k) {
     if constexpr (G == 6 || G == 7) {
       switch (diag) {
         case 1: decode_attn_long_kernel<G, 1><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); return;
@@ -726,6 +745,16 @@ static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_
 #endif
   // caches beyond 16 * DA_MAX_STEPS keys per workgroup: the barrier-free streaming kernel (chunk <= 64 * DA_STREAM_TPW = DA_LONG_MAX,
   // checked by the caller); the bounded windows: the split kernel
+#ifdef SVLM_TUNING
+  if (chunk > 16 * DA_MAX_STEPS && diag != 0) {
+    if constexpr (G == 6 || G == 7) {
+      if (diag == 1) decode_attn_stream_kernel<G, 1><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+      else if (diag == 2) decode_attn_stream_kernel<G, 2><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+      else decode_attn_stream_kernel<G, 3><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+      return;
+    }
+  }
+#endif
   if (chunk > 16 * DA_MAX_STEPS)
     decode_attn_stream_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
   else
@@ -758,6 +787,7 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
   int rc = svlm_check_launch("svlm_decode_attn_ropeload(split)");
   if (rc) return rc;
   static const int force_ds = svlm_env("SVLM_DA_COMBINE_DS") ? atoi(svlm_env("SVLM_DA_COMBINE_DS")) : 0;
+  if (force_ds < 0) return SVLM_OK;           // diagnostic build only: time the split kernel alone
   const int ns_max = (max_len + chunk - 1) / chunk;
   // measured on MI355X (tools/decode_attn_sweep.py): column halves pay from ~64 splits (7B @ window 4096: 13.8 -> 12.3 us),
   // column quarters on 16 waves from ~200 (32k keys: 26.3 -> 22.8 us); below that the extra workgroups only add latency
