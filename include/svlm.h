@@ -181,6 +181,18 @@ long long svlm_decode_attn_ws_bytes(int Hq, int max_len, int chunk);
 int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of, const void* rope_cs,
                               const int* len_dev, int len_add, void* out, void* ws, int Hq, int Hkv, int D, int n_slots,
                               int max_len, int chunk, float scale, void* stream);
+/* The same attention with the layer's LINEAR PLANES beside the pool.  The reference rotates EVERY cached key in EVERY forward
+ * (qwen2/language_forward.py:55-63, called at :103); between two evictions the positions of the cached rows do not change, so the
+ * rotated keys the prefill of a chunk produces anyway are kept (svlm_prefill_attn_ropeload_lin) and each decode step streams them:
+ *   k_lin (Hkv, lin_rows/16, 4, 64, 8) bf16  16-key tiles of ROTATED keys in logical order; inside a tile chunk c (8 values) of key r
+ *                                            sits at [c >> 2][(c & 3) * 16 + r][8], the operand layout of the decode kernels
+ *   v_lin (Hkv, lin_rows, 128) bf16          values in logical order
+ *   *lin_len_dev                             rows [0, *lin_len_dev) of both are valid; key ranges above it (the rows appended since
+ *                                            the prefill) are read from the pool and rotated as svlm_decode_attn_ropeload does
+ * lin_rows % 16 == 0, lin_rows >= max_len; all three NULL = svlm_decode_attn_ropeload.  Same bits either way. */
+int svlm_decode_attn_lin(const void* q, const void* k_planes, const void* v_planes, const int* slot_of, const void* rope_cs,
+                         const int* len_dev, int len_add, const void* k_lin, const void* v_lin, int lin_rows, const int* lin_len_dev,
+                         void* out, void* ws, int Hq, int Hkv, int D, int n_slots, int max_len, int chunk, float scale, void* stream);
 /* Prefill attention: q (T, q_stride) un-rotated rows for logical positions L-T..L-1, causal bottom-right aligned.
  * Their un-rotated K/V rows are either already in the pool (k_new = v_new = NULL, after svlm_kv_append) or handed over as
  * k_new / v_new (T, kv_new_stride) -- e.g. column slices of the fused QKV projection -- and APPENDED to their slots by the
@@ -194,6 +206,12 @@ int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_new, c
                                void* k_planes, void* v_planes, const int* slot_of, const void* rope_cs, void* out, int o_stride,
                                int T, int L, int Hq, int Hkv, int D, int n_slots, float scale, void* ws, long long ws_bytes,
                                void* stream);
+/* ... which also leaves rows [0, L) of the layer's linear planes (svlm_decode_attn_lin) behind and sets *lin_len_dev = L
+ * (k_lin, v_lin, lin_len_dev together or all NULL; lin_rows % 16 == 0, lin_rows >= L). */
+int svlm_prefill_attn_ropeload_lin(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
+                                   void* k_planes, void* v_planes, const int* slot_of, const void* rope_cs, void* out, int o_stride,
+                                   int T, int L, int Hq, int Hkv, int D, int n_slots, float scale, void* ws, long long ws_bytes,
+                                   void* k_lin, void* v_lin, int lin_rows, int* lin_len_dev, void* stream);
 
 /* seen[id] = 1 for ids[0..n).  (input to the repetition penalty) */
 int svlm_mark_seen(const int* ids, int n, void* seen, int V, void* stream);

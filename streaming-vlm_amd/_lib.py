@@ -56,6 +56,8 @@ SIGNATURES = {
     "svlm_decode_attn_ropeload": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "svlm_prefill_attn_ws_bytes": (_ll, [_i, _i, _i, _i]),
     "svlm_prefill_attn_ropeload": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _ll, _p]),
+    "svlm_prefill_attn_ropeload_lin": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _ll, _p, _p, _i, _p, _p]),
+    "svlm_decode_attn_lin": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
     "svlm_mark_seen": (_i, [_p, _i, _p, _i, _p]),
     "svlm_argmax_ws_bytes": (_ll, []),
     "svlm_penalty_argmax": (_i, [_p, _i, _p, _f, _p, _i, _p, _p, _i, _p, _p]),

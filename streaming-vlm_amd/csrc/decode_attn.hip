@@ -18,6 +18,7 @@
 // spread over waves and the loads unrolled.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define DA_D 128
 #define DA_GMAX 8
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
     const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
     float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
-    int chunk, float scale, int max_len) {
+    int chunk, float scale, int max_len, const bf16_t* __restrict__ k_lin, const bf16_t* __restrict__ v_lin, int lin_rows,
+    const int* __restrict__ lin_len_dev) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2 + 512];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(lds);
   bf16_t* Vs = Ks + 64 * DA_KLD;
@@ -79,6 +81,21 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   }
   u32x4_t qraw = u32x4_t{0, 0, 0, 0};
   if (srow < G) qraw = *reinterpret_cast<const u32x4_t*>(q + (size_t)(kvh * G + srow) * DA_D + c * 8);
+  // ---- nor do the rows of the linear planes (header of svlm_decode_attn_lin): tile (start / 16 + it) of the kv head, chunk c of key
+  // srow at [c >> 2][(c & 3) * 16 + srow][8] -- the 256 threads of one step read one whole 4 KB tile.  Requested before the lengths are
+  // known (the planes are allocated to lin_rows; whether the rows are VALID is decided below), so the common case is ONE memory
+  // latency deep: no slot table, no cos / sin rows, no rotation
+  u32x4_t kraw[DA_MAX_STEPS], vraw[DA_MAX_STEPS], craw[DA_MAX_STEPS], sraw[DA_MAX_STEPS];
+  if (k_lin != nullptr) {
+    const int n_lt = lin_rows >> 4;
+#pragma unroll
+    for (int it = 0; it < DA_MAX_STEPS; ++it) {
+      if (it * 16 >= chunk) break;
+      const int lt = min((start >> 4) + it, n_lt - 1);
+      kraw[it] = *reinterpret_cast<const u32x4_t*>(k_lin + ((size_t)kvh * n_lt + lt) * 2048 + (c >> 2) * 512 + ((c & 3) * 16 + srow) * 8);
+      vraw[it] = *reinterpret_cast<const u32x4_t*>(v_lin + ((size_t)kvh * lin_rows + lt * 16 + srow) * DA_D + c * 8);
+    }
+  }
   const int L = (len_dev ? *len_dev : 0) + len_add;
   if (start >= L) return;
   const int n_rows = min(chunk, L - start);
@@ -86,15 +103,20 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   const bf16_t* csq = rope_cs + (size_t)(L - 1) * DA_D;
   const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + fc);
   const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + fc);
-  u32x4_t kraw[DA_MAX_STEPS], vraw[DA_MAX_STEPS], craw[DA_MAX_STEPS], sraw[DA_MAX_STEPS];
+  // a key range that lies inside the valid part of the linear planes keeps the rows requested above; any other (the range that holds
+  // the rows appended since the prefill) takes them from the pool and rotates them
+  const int lin_len = (k_lin != nullptr && lin_len_dev != nullptr) ? min(*lin_len_dev, L) : 0;
+  const bool wg_lin = start + chunk <= lin_len;             // workgroup-uniform; implies n_rows == chunk
+  if (!wg_lin) {
 #pragma unroll
-  for (int it = 0; it < DA_MAX_STEPS; ++it) {
-    if (it >= n_steps) break;
-    kraw[it] = *reinterpret_cast<const u32x4_t*>(kp + (size_t)slots[it] * DA_D);
-    vraw[it] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)slots[it] * DA_D);
-    const bf16_t* csr = rope_cs + (size_t)rows[it] * DA_D;
-    craw[it] = *reinterpret_cast<const u32x4_t*>(csr + fc);
-    sraw[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
+    for (int it = 0; it < DA_MAX_STEPS; ++it) {
+      if (it >= n_steps) break;
+      kraw[it] = *reinterpret_cast<const u32x4_t*>(kp + (size_t)slots[it] * DA_D);
+      vraw[it] = *reinterpret_cast<const u32x4_t*>(vp + (size_t)slots[it] * DA_D);
+      const bf16_t* csr = rope_cs + (size_t)rows[it] * DA_D;
+      craw[it] = *reinterpret_cast<const u32x4_t*>(csr + fc);
+      sraw[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
+    }
   }
 
   // ---- stage the rotated query block (rows >= G are zero) ...
@@ -112,6 +134,15 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     *reinterpret_cast<u32x4_t*>(Qs + srow * DA_KLD + c * 8) = outq;
   }
   // ---- ... and the chunk's keys (rotated) and values; rows past the end are zero
+  if (wg_lin) {
+#pragma unroll
+    for (int it = 0; it < DA_MAX_STEPS; ++it) {
+      if (it >= n_steps) break;
+      const int lrow = it * 16 + srow;
+      *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = kraw[it];
+      *reinterpret_cast<u32x4_t*>(Vs + lrow * DA_VLD + c * 8) = vraw[it];
+    }
+  } else
 #pragma unroll
   for (int it = 0; it < DA_MAX_STEPS; ++it) {
     if (it >= n_steps) break;
@@ -415,12 +446,13 @@ struct DaTile {
   u32x4_t k[4], cs[4], v[4];     // K pieces ks = 0..3; cos pieces 0,1 and sin pieces 0,1; V rows 4 i + (lane >> 4), chunk lane & 15
 };
 
-template <int G, int DIAG = 0>       // DIAG (diagnostic build only): 1 = no cos/sin loads, no rotation; 2 = loads only, no arithmetic at all
+template <int G, int DIAG = 0, bool WLIN = false>       // WLIN: launched with linear planes (below); DIAG bits (diagnostic build only): 1 = no cos/sin loads, no rotation; 2 = loads only, no arithmetic at all; 4 = cos/sin rows from a 16 KB table
 __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
     const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs, const int* __restrict__ len_dev, int len_add,
     float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
-    int chunk, float scale, int max_len) {
+    int chunk, float scale, int max_len, const bf16_t* __restrict__ k_lin, const bf16_t* __restrict__ v_lin, int lin_rows,
+    const int* __restrict__ lin_len_dev) {
   // LDS: [4][16][128] fp32 merge buffer (32 KB), whose first 18 KB double as the four waves' V slabs during the loop; Q block; m / l
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 16 * DA_D * 4 + 16 * DA_KLD * 2 + 512];
   float* Om = reinterpret_cast<float*>(lds);
@@ -428,7 +460,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   float* Mm = reinterpret_cast<float*>(lds + 4 * 16 * DA_D * 4 + 16 * DA_KLD * 2);
   float* Lm = Mm + 64;
 
-  const int start = blockIdx.x * chunk;
+  // the LAST key range is dispatched FIRST: it is the one that holds the rows appended since the prefill (pool path below, slower per tile)
+  const int sp = gridDim.x - 1 - blockIdx.x;
+  const int start = sp * chunk;
   const int kvh = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -436,10 +470,6 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D;
   const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D;
 
-  // slot of key (lane & 15) in each of the wave's tiles (stale / clamped entries are valid slots; masked later)
-  int slot_t[DA_STREAM_TPW];
-#pragma unroll
-  for (int t = 0; t < DA_STREAM_TPW; ++t) slot_t[t] = slot_of[min(start + (t * 4 + wave) * 16 + fr, max_len - 1)];
   // rotated query block -> Qs (rows >= G are zero), exactly as the kernels above
   {
     const int srow = tid >> 4, c = tid & 15;
@@ -465,15 +495,32 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   if (start >= L) return;                                   // workgroup-uniform
   const int n_rows = min(chunk, L - start);
   const int n_tiles = (n_rows + 15) >> 4;                   // of the workgroup; wave w owns tiles w, w + 4, ...
+  // WLIN: rows [0, lin_len) of the cache also exist ROTATED, in logical order, in the linear planes the prefill left behind (header of
+  // svlm_decode_attn_lin): tiles that lie there are streamed from them (no slot table, no cos/sin rows, no rotation).  Without
+  // linear planes (!WLIN) the kernel is the pipelined pool path alone.
+  const int lin_len = WLIN ? min(*lin_len_dev, L) : 0;
   __syncthreads();                                          // Qs visible
   bf16x8_t qf[4];                                           // this lane's B fragments of the query block: constant over the loop
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + fr * DA_KLD + ks * 32 + fq * 8);
 
+  // linear planes: the 16-key tile r of kv head h is 4 KB at k_lin + (h * lin_rows / 16 + r) * 2048, laid out as the four operand loads
+  // of this kernel: [ks][lane][8] (lane = fq * 16 + key) -- every load instruction reads 1 KB of consecutive bytes; V rows are row-major
+  auto load_lin = [&](int t, DaTile& b) {
+    const int r0 = start + (t * 4 + wave) * 16;
+    const bf16_t* kt = k_lin + ((size_t)kvh * (lin_rows >> 4) + (r0 >> 4)) * 2048 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b.k[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kt + ks * 512));
+    const bf16_t* vt = v_lin + ((size_t)kvh * lin_rows + r0 + fq) * DA_D + fr * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vt + (size_t)i * 4 * DA_D));
+  };
   auto load_tile = [&](int t, int slot_own, DaTile& b) {
     // K in operand layout: piece ks of row `slot_own`; cos / sin pieces of the key's logical row
     const bf16_t* krow = kp + (size_t)slot_own * DA_D + fq * 8;
-    const int lrow = min(start + (t * 4 + wave) * 16 + fr, max_len - 1);
+    int lrow = min(start + (t * 4 + wave) * 16 + fr, max_len - 1);
+    if constexpr ((DIAG & 8) != 0) lrow = (lrow >> 4) & 63;  // timing only: the 16 keys of a tile share one cos/sin row (one cache line per load instruction)
+    if constexpr ((DIAG & 4) != 0) lrow &= 63;               // timing only: every cos/sin row from a 16 KB table (what an L1-resident table would cost)
     const bf16_t* csr = rope_cs + (size_t)lrow * DA_D + fq * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) b.k[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(krow + ks * 32));
@@ -496,7 +543,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int t, const DaTile& b) {
+  auto compute = [&](auto lin_c, int t, const DaTile& b) {
+    constexpr bool LIN = decltype(lin_c)::value;            // keys already rotated (linear planes)
     const int base = (t * 4 + wave) * 16;                   // first key of the tile, relative to `start`
     if constexpr ((DIAG & 2) != 0) {                        // timing only: every loaded register is consumed, nothing else happens
       unsigned x = 0;
@@ -512,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     }
     // ---- RoPE on registers: out(d) = bf(bf(x c) + bf(rot s)), rot = -x(d + 64) for d < 64, x(d - 64) above
     bf16x8_t kf[4];
-    if constexpr ((DIAG & 1) != 0) {
+    if constexpr ((DIAG & 1) != 0 || LIN) {
 #pragma unroll
       for (int h = 0; h < 4; ++h) { u32x4_t kk = b.k[h]; kf[h] = *reinterpret_cast<bf16x8_t*>(&kk); }
     } else {
@@ -579,17 +627,44 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   // software pipeline, two named tile buffers; a wave's tile index runs 0 .. nt - 1 (workgroup tile 4 t + wave)
   const int nt = n_tiles > wave ? (n_tiles - wave + 3) >> 2 : 0;   // tiles of this wave
   DaTile A, B;
-  if (nt > 0) load_tile(0, slot_t[0], A);
+  if constexpr (WLIN) {
+    // the wave's tiles that lie wholly below lin_len (a prefix of them: all but the one or two that hold the rows appended since the
+    // prefill) are streamed from the linear planes, pipelined; the rest come from the pool, one at a time
+    const int ntl = min(nt, max(0, ((lin_len - start) >> 4) - wave + 3) >> 2);
+    if (ntl > 0) load_lin(0, A);
 #pragma unroll
-  for (int t = 0; t < DA_STREAM_TPW; t += 2) {
-    if (t >= nt) break;                                     // wave-uniform
-    if (t + 1 < DA_STREAM_TPW) load_tile(min(t + 1, nt - 1), slot_t[t + 1 < DA_STREAM_TPW ? t + 1 : t], B);      // redundant reload at the end: harmless
-    __builtin_amdgcn_sched_barrier(0);
-    compute(t, A);
-    if (t + 1 >= nt) break;
-    if (t + 2 < DA_STREAM_TPW) load_tile(min(t + 2, nt - 1), slot_t[t + 2 < DA_STREAM_TPW ? t + 2 : t], A);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(t + 1, B);
+    for (int t = 0; t < DA_STREAM_TPW; t += 2) {
+      if (t >= ntl) break;                                  // wave-uniform
+      if (t + 1 < DA_STREAM_TPW) load_lin(min(t + 1, ntl - 1), B);      // redundant reload at the end: harmless
+      __builtin_amdgcn_sched_barrier(0);
+      compute(std::true_type{}, t, A);
+      if (t + 1 >= ntl) break;
+      if (t + 2 < DA_STREAM_TPW) load_lin(min(t + 2, ntl - 1), A);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(std::true_type{}, t + 1, B);
+    }
+    for (int t = ntl; t < nt; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a trailing redundant load of the loop above may still be writing A
+      load_tile(t, slot_of[min(start + (t * 4 + wave) * 16 + fr, max_len - 1)], A);
+      compute(std::false_type{}, t, A);
+    }
+  } else {
+    // slot of key (lane & 15) in each of the wave's tiles (stale / clamped entries are valid slots; masked later)
+    int slot_t[DA_STREAM_TPW];
+#pragma unroll
+    for (int t = 0; t < DA_STREAM_TPW; ++t) slot_t[t] = slot_of[min(start + (t * 4 + wave) * 16 + fr, max_len - 1)];
+    if (nt > 0) load_tile(0, slot_t[0], A);
+#pragma unroll
+    for (int t = 0; t < DA_STREAM_TPW; t += 2) {
+      if (t >= nt) break;                                   // wave-uniform
+      if (t + 1 < DA_STREAM_TPW) load_tile(min(t + 1, nt - 1), slot_t[t + 1 < DA_STREAM_TPW ? t + 1 : t], B);      // redundant reload at the end: harmless
+      __builtin_amdgcn_sched_barrier(0);
+      compute(std::false_type{}, t, A);
+      if (t + 1 >= nt) break;
+      if (t + 2 < DA_STREAM_TPW) load_tile(min(t + 2, nt - 1), slot_t[t + 2 < DA_STREAM_TPW ? t + 2 : t], A);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(std::false_type{}, t + 1, B);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // trailing redundant loads must not outlive the registers
   __syncthreads();                                          // every wave is done with its V slab: the region becomes the merge buffer
@@ -599,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
   }
   __syncthreads();
-  const size_t part = (size_t)blockIdx.x * Hq;
+  const size_t part = (size_t)sp * Hq;
   for (int idx = tid; idx < G * DA_D; idx += 256) {
     const int g = idx / DA_D, d = idx % DA_D;
     float mn = Mm[g];
@@ -722,7 +797,7 @@ extern "C" long long svlm_decode_attn_ws_bytes(int Hq, int max_len, int chunk) {
 template <int G>
 static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_t* kp, const bf16_t* vp, const int* slot_of,
                          const bf16_t* cs, const int* len_dev, int len_add, float* ws_m, float* ws_l, float* ws_acc, int Hq, int Hkv,
-                         int n_slots, int chunk, float scale, int max_len) {
+                         int n_slots, int chunk, float scale, int max_len, const bf16_t* k_lin, const bf16_t* v_lin, int lin_rows, const int* lin_len) {
 #ifdef SVLM_TUNING
   // diagnostic build only: the multi-pass long-cache kernel the streaming kernel replaced, and its timing-only DIAG variants
   static const int diag = svlm_env("SVLM_DA_DIAG") ? atoi(svlm_env("SVLM_DA_DIAG")) : 0;
@@ -748,22 +823,43 @@ static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_
 #ifdef SVLM_TUNING
   if (chunk > 16 * DA_MAX_STEPS && diag != 0) {
     if constexpr (G == 6 || G == 7) {
-      if (diag == 1) decode_attn_stream_kernel<G, 1><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
-      else if (diag == 2) decode_attn_stream_kernel<G, 2><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
-      else decode_attn_stream_kernel<G, 3><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+      if (diag == 1) decode_attn_stream_kernel<G, 1><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
+      else if (diag == 2) decode_attn_stream_kernel<G, 2><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
+      else if (diag == 3) decode_attn_stream_kernel<G, 3><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
+      else if (diag == 8) decode_attn_stream_kernel<G, 8><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
+      else if (diag == 4) decode_attn_stream_kernel<G, 4><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
+      else decode_attn_stream_kernel<G, 6><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
       return;
     }
   }
 #endif
-  if (chunk > 16 * DA_MAX_STEPS)
-    decode_attn_stream_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+  if (chunk > 16 * DA_MAX_STEPS && k_lin != nullptr)
+    decode_attn_stream_kernel<G, 0, true><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
+  else if (chunk > 16 * DA_MAX_STEPS)
+    decode_attn_stream_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
   else
-    decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len);
+    decode_attn_split_kernel<G><<<grid, 256, 0, st>>>(q, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, k_lin, v_lin, lin_rows, lin_len);
 }
 
-extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of,
-                                         const void* rope_cs, const int* len_dev, int len_add, void* out, void* ws,
-                                         int Hq, int Hkv, int D, int n_slots, int max_len, int chunk, float scale, void* stream) {
+// The same attention with the LINEAR PLANES of the layer beside the pool.  The reference rotates every cached key in every forward
+// (language_forward.py:55-63); between two evictions the positions of the cached rows do not change, so the rotated keys the prefill
+// of a chunk has to produce anyway (rope_gather_kernel, flash_attn.hip) are kept -- svlm_prefill_attn_ropeload_lin -- and every decode
+// step of the chunk streams them instead of rotating the pool rows again:
+//   k_lin  (Hkv, lin_rows / 16, 4, 64, 8) bf16: 16-key tiles of ROTATED keys in logical order, each tile laid out as the four MFMA
+//          operand loads of the decode kernels ([ks][lane = fq * 16 + key][8]: one load instruction = 1 KB of consecutive bytes)
+//   v_lin  (Hkv, lin_rows, 128) bf16: values in logical order
+//   *lin_len_dev: rows [0, *lin_len_dev) of both are valid (written by the prefill; the host lowers it when it edits the logical order)
+// A workgroup whose whole key range lies below *lin_len_dev reads no slot table, no cos / sin rows and rotates nothing; any other (the
+// range with the rows appended since the prefill: at most max_new_tokens of them) takes the pool path.  Same bits either way: the
+// rotation arithmetic of the two producers is the same expression.
+extern "C" int svlm_decode_attn_lin(const void* q, const void* k_planes, const void* v_planes, const int* slot_of,
+                                    const void* rope_cs, const int* len_dev, int len_add, const void* k_lin, const void* v_lin,
+                                    int lin_rows, const int* lin_len_dev, void* out, void* ws,
+                                    int Hq, int Hkv, int D, int n_slots, int max_len, int chunk, float scale, void* stream) {
+  SVLM_CHECK_ARG((k_lin == nullptr) == (v_lin == nullptr) && (k_lin == nullptr) == (lin_len_dev == nullptr),
+                 "svlm_decode_attn_lin: k_lin, v_lin and lin_len_dev come together");
+  SVLM_CHECK_ARG(k_lin == nullptr || (lin_rows > 0 && lin_rows % 16 == 0 && lin_rows >= max_len),
+                 "svlm_decode_attn_lin: lin_rows=%d must be a multiple of 16 and >= max_len=%d", lin_rows, max_len);
   SVLM_CHECK_ARG(D == DA_D, "svlm_decode_attn_ropeload: head_dim %d unsupported (128 only)", D);
   SVLM_CHECK_ARG(Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Hq / Hkv <= DA_GMAX, "svlm_decode_attn_ropeload: Hq=%d Hkv=%d (group must be <= %d)", Hq, Hkv, DA_GMAX);
   SVLM_CHECK_ARG(chunk > 0 && max_len > 0 && n_slots > 0 &&
@@ -779,7 +875,7 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
   hipStream_t st = (hipStream_t)stream;
   const bf16_t *qq = (const bf16_t*)q, *kp = (const bf16_t*)k_planes, *vp = (const bf16_t*)v_planes, *cs = (const bf16_t*)rope_cs;
 #define SVLM_DA_CASE(GG) \
-  case GG: launch_split<GG>(grid, st, qq, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len); break;
+  case GG: launch_split<GG>(grid, st, qq, kp, vp, slot_of, cs, len_dev, len_add, ws_m, ws_l, ws_acc, Hq, Hkv, n_slots, chunk, scale, max_len, (const bf16_t*)k_lin, (const bf16_t*)v_lin, lin_rows, lin_len_dev); break;
   switch (Hq / Hkv) {
     SVLM_DA_CASE(1) SVLM_DA_CASE(2) SVLM_DA_CASE(3) SVLM_DA_CASE(4) SVLM_DA_CASE(5) SVLM_DA_CASE(6) SVLM_DA_CASE(7) SVLM_DA_CASE(8)
   }
@@ -799,4 +895,11 @@ extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, co
     decode_attn_combine_kernel<4, 1><<<Hq, 256, 0, st>>>(ws_m, ws_l, ws_acc, len_dev, len_add, (bf16_t*)out, Hq, chunk, ns_max);
   }
   return svlm_check_launch("svlm_decode_attn_ropeload(combine)");
+}
+
+extern "C" int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v_planes, const int* slot_of,
+                                         const void* rope_cs, const int* len_dev, int len_add, void* out, void* ws,
+                                         int Hq, int Hkv, int D, int n_slots, int max_len, int chunk, float scale, void* stream) {
+  return svlm_decode_attn_lin(q, k_planes, v_planes, slot_of, rope_cs, len_dev, len_add, nullptr, nullptr, 0, nullptr, out, ws, Hq, Hkv, D,
+                              n_slots, max_len, chunk, scale, stream);
 }

@@ -687,10 +687,15 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
                                                           bf16_t* __restrict__ k_planes, bf16_t* __restrict__ v_planes,
                                                           const int* __restrict__ slot_of, const bf16_t* __restrict__ rope_cs,
                                                           bf16_t* __restrict__ q_rot, bf16_t* __restrict__ k_rot,
-                                                          bf16_t* __restrict__ v_lin, int T, int L, int Hq, int Hkv, int n_slots) {
+                                                          bf16_t* __restrict__ v_lin, int T, int L, int Hq, int Hkv, int n_slots,
+                                                          bf16_t* __restrict__ k_keep, bf16_t* __restrict__ v_keep, int lin_rows,
+                                                          int* __restrict__ lin_len_dev) {
+  // k_keep / v_keep (optional): the layer's LINEAR PLANES, which outlive the prefill -- the decode steps of the chunk stream the
+  // rotated keys from there instead of rotating the pool rows again (layout and contract: svlm_decode_attn_lin, decode_attn.hip)
   constexpr int D = 128, CPR = 16;
   const long nk = (long)Hkv * L * CPR, nq = (long)T * Hq * CPR;
   const long total = 2 * nk + nq;
+  if (lin_len_dev != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *lin_len_dev = L;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     if (i >= nk && i < 2 * nk) {                      // V: plain gather (new rows: taken from the projection output and APPENDED)
       const long t = i - nk;
@@ -704,10 +709,12 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
         v = *reinterpret_cast<const u32x4_t*>(slot_p);
       }
       *reinterpret_cast<u32x4_t*>(v_lin + ((size_t)h * L + j) * D + c * 8) = v;
+      if (v_keep != nullptr) *reinterpret_cast<u32x4_t*>(v_keep + ((size_t)h * lin_rows + j) * D + c * 8) = v;
       continue;
     }
     const bf16_t* src;
     bf16_t* dst;
+    bf16_t* keep = nullptr;
     int c, pos;
     if (i < nk) {
       c = (int)(i % CPR);
@@ -719,6 +726,8 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
         *reinterpret_cast<u32x4_t*>(slot_p + c * 8) = *reinterpret_cast<const u32x4_t*>(src + c * 8);
       }
       dst = k_rot + ((size_t)h * L + j) * D;
+      if (k_keep != nullptr)        // tile j / 16 of the kv head, chunk c of key j % 16 at [c >> 2][(c & 3) * 16 + j % 16][8]
+        keep = k_keep + ((size_t)h * (lin_rows >> 4) + (j >> 4)) * 2048 + (c >> 2) * 512 + ((c & 3) * 16 + (j & 15)) * 8;
       pos = j;
     } else {
       const long t = i - 2 * nk;
@@ -740,7 +749,9 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
       const float rot = upper ? xp[e] : -xp[e];
       o[e] = rbf(rbf(x[e] * cc[e]) + rbf(rot * sn[e]));
     }
-    *reinterpret_cast<u32x4_t*>(dst + c * 8) = pack8(o);
+    const u32x4_t ov = pack8(o);
+    *reinterpret_cast<u32x4_t*>(dst + c * 8) = ov;
+    if (keep != nullptr) *reinterpret_cast<u32x4_t*>(keep) = ov;
   }
 }
 
@@ -752,10 +763,17 @@ extern "C" long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv) {
 }
 
 // LLM prefill: q (T, Hq*128) un-rotated rows, pool planes of one layer, out (T, Hq*128).
-extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
-                                          void* k_planes, void* v_planes, const int* slot_of,
-                                          const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D,
-                                          int n_slots, float scale, void* ws, long long ws_bytes, void* stream) {
+// k_lin / v_lin / lin_len_dev (optional, together): the layer's linear planes of lin_rows rows (svlm_decode_attn_lin); the launch that
+// rotates and gathers the keys for this prefill also leaves them there and sets *lin_len_dev = L.
+extern "C" int svlm_prefill_attn_ropeload_lin(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
+                                              void* k_planes, void* v_planes, const int* slot_of,
+                                              const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D,
+                                              int n_slots, float scale, void* ws, long long ws_bytes, void* k_lin, void* v_lin_keep,
+                                              int lin_rows, int* lin_len_dev, void* stream) {
+  SVLM_CHECK_ARG((k_lin == nullptr) == (v_lin_keep == nullptr) && (k_lin == nullptr) == (lin_len_dev == nullptr),
+                 "svlm_prefill_attn_ropeload_lin: k_lin, v_lin and lin_len_dev come together");
+  SVLM_CHECK_ARG(k_lin == nullptr || (lin_rows > 0 && lin_rows % 16 == 0 && lin_rows >= L),
+                 "svlm_prefill_attn_ropeload_lin: lin_rows=%d must be a multiple of 16 and >= L=%d", lin_rows, L);
   SVLM_CHECK_ARG((k_new == nullptr) == (v_new == nullptr) && (k_new == nullptr || (kv_new_stride % 8 == 0 && kv_new_stride >= Hkv * D)),
                  "svlm_prefill_attn_ropeload: k_new / v_new come as a pair with a 16-B aligned row stride >= Hkv*D (stride %d)", kv_new_stride);
   SVLM_CHECK_ARG(D == 128, "svlm_prefill_attn_ropeload: head_dim %d unsupported (128 only)", D);
@@ -774,7 +792,8 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   g = g > 4096 ? 4096 : g;
   rope_gather_kernel<<<g, 256, 0, st>>>((const bf16_t*)q, q_stride, (const bf16_t*)k_new, (const bf16_t*)v_new, kv_new_stride,
                                        (bf16_t*)k_planes, (bf16_t*)v_planes, slot_of,
-                                       (const bf16_t*)rope_cs, q_rot, k_rot, v_lin, T, L, Hq, Hkv, n_slots);
+                                       (const bf16_t*)rope_cs, q_rot, k_rot, v_lin, T, L, Hq, Hkv, n_slots, (bf16_t*)k_lin, (bf16_t*)v_lin_keep,
+                                       lin_rows, lin_len_dev);
   int rc = svlm_check_launch("svlm_prefill_attn_ropeload(rope_gather)");
   if (rc) return rc;
   const int ns = prefill_splits(T, L, Hq);
@@ -821,6 +840,14 @@ extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const voi
   const long n_thr = (long)T * Hq * 32;
   flash_combine_kernel<<<(int)((n_thr + 255) / 256), 256, 0, st>>>(part_o, part_ml, (bf16_t*)out, o_stride, T, Hq, ns, scale);
   return svlm_check_launch("svlm_prefill_attn_ropeload(combine)");
+}
+
+extern "C" int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
+                                          void* k_planes, void* v_planes, const int* slot_of,
+                                          const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D,
+                                          int n_slots, float scale, void* ws, long long ws_bytes, void* stream) {
+  return svlm_prefill_attn_ropeload_lin(q, q_stride, k_new, v_new, kv_new_stride, k_planes, v_planes, slot_of, rope_cs, out, o_stride, T, L, Hq,
+                                        Hkv, D, n_slots, scale, ws, ws_bytes, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // ViT: qkv (N, 3, H, d) fused buffer already rotated by svlm_vit_rope; n_seq sequences of seq_len rows.

@@ -245,13 +245,16 @@ class SvlmEngine:
     def __init__(self, cfg: ModelConfig, state_dict, device="cuda", ops=None, max_len: int = 4096, max_new_tokens: int = 32,
                  decode_chunk: Optional[int] = None, use_graph: Optional[bool] = None, kv_slack: float = 1.0, kv_page_tokens: int = 16,
                  decode_tail: Optional[bool] = None,
-                 vit_fp8: bool = False):
+                 vit_fp8: bool = False, linear_planes: Optional[bool] = None):
         if ops is None:
             from .ops import HipOps
             ops = HipOps()                      # raises when the HIP extension / GPU is missing
         self.ops = ops
         self.cfg = cfg
         self.device = torch.device(device)
+        # the cache keeps the rotated keys / values the prefill gathers (kv_pool.py: linear planes) and the decode steps stream them;
+        # False: no second copy of the K/V rows, every decode step rotates the pool rows (same bits)
+        self.linear_planes = (os.environ.get("SVLM_LINEAR_PLANES", "1") != "0") if linear_planes is None else bool(linear_planes)
         self.w = EngineWeights(state_dict, cfg, self.device)
         tc, vc = cfg.text, cfg.vision
         if tc.head_dim != 128 or sum(tc.mrope_section) * 2 != tc.head_dim:
@@ -366,7 +369,8 @@ class SvlmEngine:
     def new_cache(self, page_tokens: Optional[int] = None, slack: Optional[float] = None) -> KVPool:
         tc = self.cfg.text
         return KVPool(tc.num_layers, tc.num_kv_heads, tc.head_dim, self.max_len, self.device, self.ops,
-                      self.kv_page_tokens if page_tokens is None else page_tokens, self.kv_slack if slack is None else slack)
+                      self.kv_page_tokens if page_tokens is None else page_tokens, self.kv_slack if slack is None else slack,
+                      linear_planes=self.linear_planes)
 
     # ------------------------------------------------------------------ ViT
     def _vit_rope(self, grid_thw):
@@ -515,12 +519,15 @@ class SvlmEngine:
         hm = torch.empty((T, tc.intermediate_size), dtype=BF16, device=dev)
         scale = 1.0 / math.sqrt(tc.head_dim)
         n_layers = len(w.layers)
+        # the gather launch of every layer also leaves the rotated keys / values of rows [0, L) in the cache's linear planes, which the
+        # decode steps of this chunk stream instead of rotating the pool rows again (kv_pool.py)
+        lin = c.lin_args() if hasattr(c, "lin_args") else None
         o.rmsnorm(x, w.layers[0]["ln1"], tc.rms_eps, out=xn)
         for li, lw in enumerate(w.layers):
             o.gemm(xn, lw["qkv_w"], bias=lw["qkv_b"], out=qkv)
             # the chunk's K/V rows go to their pool slots inside the launch that rotates and gathers the keys
             o.prefill_attn(qkv[:, :qd], c.pool, li, c.slot_of_dev, self.rope_cs, attn, T, L, tc.num_heads, scale,
-                           k_new=qkv[:, qd:qd + kd], v_new=qkv[:, qd + kd:])
+                           k_new=qkv[:, qd:qd + kd], v_new=qkv[:, qd + kd:], lin=lin)
             # the two residual-stream GEMMs hand their output row to the RMSNorm that follows inside their split-K reduce
             o.gemm_norm(attn, lw["o_w"], lw["ln2"], tc.rms_eps, x, xn, residual=x)
             if H % 64 == 0:            # gate and up columns paired inside the GEMM tile: SwiGLU in its epilogue, no (T, 2I) round trip
@@ -532,6 +539,8 @@ class SvlmEngine:
                 o.gemm_norm(hm, lw["down_w"], w.layers[li + 1]["ln1"], tc.rms_eps, x, xn, residual=x)
             else:
                 o.gemm(hm, lw["down_w"], residual=x, out=x)
+        if lin is not None:
+            c.lin_written(L)
         if not head:
             return
         last = x[T - 1:T].contiguous()
@@ -545,6 +554,7 @@ class SvlmEngine:
         H, qd, kd = tc.hidden_size, self.qd, self.kd
         kv_len = self.state[0:1]
         scale = 1.0 / math.sqrt(tc.head_dim)
+        lin = c.lin_args() if hasattr(c, "lin_args") else None        # rows below *lin_len: streamed from the prefill's rotated copy
         o.gather_rows(w.embed, None, self.tok_buf, self.d_x.view(1, H), idx_off=self.state[1:2])
         if self.decode_tail:
             # 3 launches per layer: [attn split] [attn combine] [tail: o+res, norm+gate/up+SwiGLU, down+res, next layer's norm+QKV+append]
@@ -554,7 +564,7 @@ class SvlmEngine:
             o.dec_qkv(self.d_x, l0["ln1"], tc.rms_eps, l0["qkv_w"], l0["qkv_b"], self.d_qkv, c.pool, 0, c.slot_of_dev, qd, kd, len_dev=kv_len)
             for li, lw in enumerate(w.layers):
                 o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
-                              self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
+                              self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len, lin=lin)
                 nxt = None
                 if li + 1 < nl:
                     ln = w.layers[li + 1]
@@ -564,7 +574,7 @@ class SvlmEngine:
             o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
                       len_dev=kv_len)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
-                          self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len)
+                          self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len, lin=lin)
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)
             o.dec_gate_up(self.d_x, lw["ln2"], tc.rms_eps, lw["gu_w"], self.d_h)
             o.gemv(self.d_h, lw["down_w"], residual=self.d_x, out=self.d_x)

@@ -8,6 +8,12 @@ bounded stream; ``slot_of[i]`` (int32) maps logical token i to its slot.  Slots 
 pages of ``page_tokens`` consecutive rows so a chunk's rows stay contiguous; eviction and the
 assistant-text move edit ``slot_of`` on the host (O(L) int32) and free whole pages when their
 last live row goes; bytes move only on append and when ``defragment`` packs sparse pages.
+
+Beside the pool the cache holds its LINEAR PLANES ``lin[layer][kv][Hkv][lin_rows][D]``: the rotated keys (in the decode kernels'
+operand layout) and the values of rows ``[0, lin_valid)`` in logical order, as the prefill of the current chunk gathered them
+(``svlm_prefill_attn_ropeload_lin``).  The reference rotates every cached key in every forward (qwen2/language_forward.py:55-63);
+the positions of cached rows only change when the host edits the logical order, so the decode steps of a chunk stream that copy
+(``svlm_decode_attn_lin``) and take only the rows appended since from the pool.  Every edit of the logical order lowers ``lin_valid``.
 """
 from __future__ import annotations
 
@@ -44,8 +50,9 @@ class KVPool:
     _next_serial = 0          # pools are numbered: a captured decode graph is keyed by the serial of the pool whose buffers it holds
 
     def __init__(self, n_layers: int, n_kv_heads: int, head_dim: int, max_len: int, device, ops, page_tokens: int = 16,
-                 slack: float = 1.0):
-        """max_len: the largest logical length the stream ever reaches (sink + window + one chunk)."""
+                 slack: float = 1.0, linear_planes: bool = True):
+        """max_len: the largest logical length the stream ever reaches (sink + window + one chunk).
+        linear_planes=False: no rotated copy (saves max_len rows of K and V per layer; every decode step then rotates the pool rows)."""
         self.n_layers, self.Hkv, self.D = n_layers, n_kv_heads, head_dim
         self.P = page_tokens
         self.max_len = int(max_len)
@@ -71,8 +78,29 @@ class KVPool:
         # pos_mode="append": the M-RoPE position of every cached row, edited in lockstep with slot_of (float64 holds the
         # int positions of Qwen2-VL and the float32 ones of Qwen2.5-VL exactly)
         self.pos_rows = np.zeros((3, self.max_len), dtype=np.float64)
+        # linear planes (module docstring): rows never read above lin_valid, so no initialisation
+        self.lin_rows = -(-self.max_len // 16) * 16
+        self.lin = torch.empty((n_layers, 2, n_kv_heads, self.lin_rows, head_dim), dtype=torch.bfloat16, device=device) if linear_planes else None
+        self.lin_len_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.lin_valid = 0        # host mirror of *lin_len_dev
+        self._lin_dirty = False   # lin_valid lowered on the host since the device copy was written
         self._half = {}           # layer -> (which, rows): one plane assigned, waiting for its partner
         self._upd_rows = 0        # rows of an update() pass that has not reached the last layer yet
+
+    # ------------------------------------------------------------------ linear planes
+    def lin_args(self):
+        """(planes, lin_len_dev) for ops.prefill_attn / ops.decode_attn, or None without linear planes."""
+        return None if self.lin is None else (self.lin, self.lin_len_dev)
+
+    def lin_written(self, L: int):
+        """The prefill's gather launches have left rows [0, L) of every layer in the linear planes (and L in *lin_len_dev)."""
+        if self.lin is not None:
+            self.lin_valid, self._lin_dirty = int(L), False
+
+    def _lin_touch(self, first_row: int):
+        """Logical rows >= first_row no longer are what the linear planes hold."""
+        if first_row < self.lin_valid:
+            self.lin_valid, self._lin_dirty = max(int(first_row), 0), True
 
     # ------------------------------------------------------------------ allocation
     def _take_slot(self) -> int:
@@ -134,6 +162,7 @@ class KVPool:
         self.length -= n
         self.reserved = self.length
         self._dirty_from = min(self._dirty_from, start)
+        self._lin_touch(start)
         self.stats["evicted_rows"] += n
 
     def move(self, src_s: int, src_e: int, dst: int):
@@ -150,6 +179,7 @@ class KVPool:
         pr[:, dst + 1:dst + 1 + seg.size] = pseg
         pr[:, dst + 1 + seg.size:src_e + 1] = pmid
         self._dirty_from = min(self._dirty_from, dst + 1)
+        self._lin_touch(dst + 1)
 
     def truncate(self, new_length: int):
         assert self.reserved == self.length and 0 <= new_length <= self.length
@@ -163,6 +193,9 @@ class KVPool:
         if lo < hi:
             self.slot_of_dev[lo:hi].copy_(torch.from_numpy(self.slot_of[lo:hi].copy()))
         self._dirty_from = self.max_len
+        if self._lin_dirty:
+            self.lin_len_dev.fill_(self.lin_valid)
+            self._lin_dirty = False
 
     def fragmentation(self) -> float:
         """Fraction of slots of non-free pages that hold no live row."""
@@ -236,6 +269,7 @@ class KVPool:
             raise ValueError(f"layer {layer}: key_cache[i] and value_cache[i] must be assigned as a pair of equal length")
         k, v = (other[1], r) if which == 1 else (r, other[1])
         n = k.shape[0]
+        self._lin_touch(0)        # the layer's rows are rewritten behind the linear planes' back
         if n != self.length:
             self.release_reserved()
             if n < self.length:
@@ -256,6 +290,7 @@ class KVPool:
         if layer_idx == 0:
             if self._upd_rows:
                 raise RuntimeError("update(): the previous pass did not reach the last layer")
+            self._lin_touch(self.length)      # rows appended here exist in the pool only
             self.release_reserved()
             self.reserve(T)
             self.sync_device()

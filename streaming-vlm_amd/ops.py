@@ -426,9 +426,21 @@ class HipOps:
             raise _lib.SvlmError("svlm_decode_attn_ws_bytes: bad arguments")
         return torch.empty((nbytes // 4,), dtype=torch.float32, device=device)
 
-    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None):
+    @staticmethod
+    def _lin_args(lin, layer, Hkv, D, need_rows, what):
+        """lin = (planes (n_layers, 2, Hkv, lin_rows, D) bf16, lin_len_dev int32[1]) or None -> (k_lin, v_lin, lin_rows, lin_len_dev)"""
+        if lin is None:
+            return None, None, 0, None
+        planes, lin_len = lin
+        _req(planes, BF16, what + ".lin", 5); _req(lin_len, torch.int32, what + ".lin_len", 1)
+        assert planes.shape[1] == 2 and planes.shape[2] == Hkv and planes.shape[4] == D and planes.is_contiguous(), tuple(planes.shape)
+        assert planes.shape[3] % 16 == 0 and planes.shape[3] >= need_rows, (planes.shape[3], need_rows)
+        return planes[layer, 0], planes[layer, 1], planes.shape[3], lin_len
+
+    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None, lin=None):
         """length = host-known KV length INCLUDING the appended row (len_dev None), or the constant
-        added to *len_dev (normally 1)."""
+        added to *len_dev (normally 1).  lin: the cache's linear planes (KVPool.lin_args()): key ranges below *lin_len are streamed
+        from the rotated copy the prefill left there (svlm_decode_attn_lin)."""
         _req(q, BF16, "decode_attn.q"); _req(out, BF16, "decode_attn.out"); _req(ws, torch.float32, "decode_attn.ws", 1)
         _req(rope_cs, BF16, "decode_attn.rope_cs", 2); _req(slot_of, torch.int32, "decode_attn.slot_of", 1)
         _, _, Hkv, n_slots, D = pool.shape
@@ -439,14 +451,16 @@ class HipOps:
         if len_dev is None:
             assert 0 < length <= max_len, (length, max_len)
         kp, vp = self._planes(pool, layer)
-        check(self.lib.svlm_decode_attn_ropeload(_ptr(q), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(rope_cs), _ptr(len_dev), length,
-                                                 _ptr(out), _ptr(ws), Hq, Hkv, D, n_slots, max_len, chunk, float(scale), _stream()),
-              "svlm_decode_attn_ropeload")
+        kl, vl, lin_rows, lin_len = self._lin_args(lin, layer, Hkv, D, max_len, "decode_attn")
+        check(self.lib.svlm_decode_attn_lin(_ptr(q), _ptr(kp), _ptr(vp), _ptr(slot_of), _ptr(rope_cs), _ptr(len_dev), length,
+                                            _ptr(kl), _ptr(vl), lin_rows, _ptr(lin_len), _ptr(out), _ptr(ws), Hq, Hkv, D, n_slots, max_len,
+                                            chunk, float(scale), _stream()), "svlm_decode_attn_lin")
         return out
 
-    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale, k_new=None, v_new=None):
+    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale, k_new=None, v_new=None, lin=None):
         """k_new / v_new (T, Hkv*D) row views: the chunk's un-rotated K/V rows, appended to their slots by the same launch that
-        rotates the keys (otherwise they must already be in the pool, `kv_append`)."""
+        rotates the keys (otherwise they must already be in the pool, `kv_append`).  lin: the cache's linear planes
+        (KVPool.lin_args()): the rotated keys / gathered values of rows [0, L) are left there for the decode steps."""
         _req(q, BF16, "prefill_attn.q", 2); _req(out, BF16, "prefill_attn.out", 2)
         _req(rope_cs, BF16, "prefill_attn.rope_cs", 2); _req(slot_of, torch.int32, "prefill_attn.slot_of", 1)
         _, _, Hkv, n_slots, D = pool.shape
@@ -465,9 +479,11 @@ class HipOps:
             assert k_new.shape[0] >= T and k_new.shape[1] == Hkv * D == v_new.shape[1] and k_new.stride(1) == 1 == v_new.stride(1)
             assert k_new.stride(0) == v_new.stride(0)
             kv_stride = k_new.stride(0)
-        check(self.lib.svlm_prefill_attn_ropeload(_ptr(q), q.stride(0), _ptr(k_new), _ptr(v_new), kv_stride, _ptr(kp), _ptr(vp),
-                                                  _ptr(slot_of), _ptr(rope_cs), _ptr(out), out.stride(0), T, L, Hq, Hkv, D, n_slots,
-                                                  float(scale), _ptr(ws), ws.numel() * 2, _stream()), "svlm_prefill_attn_ropeload")
+        kl, vl, lin_rows, lin_len = self._lin_args(lin, layer, Hkv, D, L, "prefill_attn")
+        check(self.lib.svlm_prefill_attn_ropeload_lin(_ptr(q), q.stride(0), _ptr(k_new), _ptr(v_new), kv_stride, _ptr(kp), _ptr(vp),
+                                                      _ptr(slot_of), _ptr(rope_cs), _ptr(out), out.stride(0), T, L, Hq, Hkv, D, n_slots,
+                                                      float(scale), _ptr(ws), ws.numel() * 2, _ptr(kl), _ptr(vl), lin_rows, _ptr(lin_len),
+                                                      _stream()), "svlm_prefill_attn_ropeload_lin")
         return out
 
     # ------------------------------------------------------------------ sampling

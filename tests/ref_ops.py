@@ -181,17 +181,50 @@ class RefOps:
         qr = self._rot(q, rope_cs, rows[L - T:])
         return om.flash_attention(qr, Kr, Vr, L - T, scale)
 
-    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None):
+    # ---- linear planes (include/svlm.h: svlm_decode_attn_lin): 16-key tiles of rotated keys, chunk c of key r at [c >> 2][(c & 3) * 16 + r][8]
+    @staticmethod
+    def lin_k_tiles(Kr, lin_rows):
+        """Kr (Hkv, L, 128) rotated keys in logical order -> (Hkv, lin_rows, 128) storage of the K plane (rows >= L zero)."""
+        Hkv, L, D = Kr.shape
+        pad = torch.zeros((Hkv, lin_rows, D), dtype=Kr.dtype)
+        pad[:, :L] = Kr
+        t = pad.view(Hkv, lin_rows // 16, 16, 4, 4, 8)            # [h][tile][r][ks][fq][8]
+        return t.permute(0, 1, 3, 4, 2, 5).reshape(Hkv, lin_rows, D).contiguous()       # [h][tile][ks][fq][r][8]
+
+    @staticmethod
+    def lin_k_rows(plane, L):
+        """inverse of lin_k_tiles: the K plane's storage -> (Hkv, L, 128) rotated keys."""
+        Hkv, lin_rows, D = plane.shape
+        t = plane.view(Hkv, lin_rows // 16, 4, 4, 16, 8).permute(0, 1, 4, 2, 3, 5)
+        return t.reshape(Hkv, lin_rows, D)[:, :L]
+
+    def decode_attn(self, q, pool, layer, slot_of, rope_cs, out, ws, Hq, max_len, chunk, scale, length=0, len_dev=None, lin=None):
         L = (int(len_dev[0]) if len_dev is not None else 0) + length
         D = pool.shape[-1]
+        if lin is not None:
+            # the rows the kernel would stream from the linear planes must be what the pool path produces: this is the check of the
+            # host's bookkeeping (every edit of the logical order has to lower *lin_len)
+            planes, lin_len = lin
+            n = min(int(lin_len[0]), L)
+            if n:
+                sl = slot_of[:n].long()
+                Kr = self._rot(pool[layer, 0][:, sl], rope_cs, torch.arange(n))
+                assert torch.equal(self.lin_k_rows(planes[layer, 0], n), Kr), f"stale rotated keys in the linear planes (layer {layer}, {n} rows)"
+                assert torch.equal(planes[layer, 1][:, :n], pool[layer, 1][:, sl]), f"stale values in the linear planes (layer {layer}, {n} rows)"
         o = self._attend(q.view(Hq, 1, D), pool, layer, slot_of, rope_cs, 1, L, Hq, scale)
         out.copy_(o.reshape(out.shape))
         return out
 
-    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale, k_new=None, v_new=None):
+    def prefill_attn(self, q, pool, layer, slot_of, rope_cs, out, T, L, Hq, scale, k_new=None, v_new=None, lin=None):
         D = pool.shape[-1]
         if k_new is not None:
             self.kv_append(k_new, v_new, pool, layer, slot_of, L - T, T)
+        if lin is not None:
+            planes, lin_len = lin
+            sl = slot_of[:L].long()
+            planes[layer, 0] = self.lin_k_tiles(self._rot(pool[layer, 0][:, sl], rope_cs, torch.arange(L)), planes.shape[3])
+            planes[layer, 1][:, :L] = pool[layer, 1][:, sl]
+            lin_len[0] = L
         o = self._attend(q[:T].reshape(T, Hq, D).transpose(0, 1), pool, layer, slot_of, rope_cs, T, L, Hq, scale)
         out[:T] = o.transpose(0, 1).reshape(T, Hq * D)
         return out
