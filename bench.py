@@ -387,6 +387,10 @@ def roofline_pass(model, args, kv_len):
     c.commit(L)
     c.sync_device()
     c.pool.normal_()                     # random rows: zero-filled operands read high (lower toggle rate -> higher clock)
+    lin = c.lin_args()
+    if lin is not None:                  # the decode step in the MIDDLE of a chunk: the prefill's rotated copy covers all but the rows decoded since
+        c.lin.normal_()
+        c.lin_len_dev.fill_(max(L - (args.new_tokens - 1) // 2, 0))
     pos = torch.arange(L + 1, dtype=torch.int32, device=dev).repeat(3, 1)
     eng.pos3_dev[:, :L + 1].copy_(pos)
     o.mrope_table(eng.pos3_dev, eng.inv_freq, eng.rope_cs, 0, L + 1, tc.mrope_section)
@@ -428,7 +432,7 @@ def roofline_pass(model, args, kv_len):
     attn_bytes = 2 * (L + 1) * Hkv * D * 2 + (L + 1) * 3 * 4 + 2 * Hq * D * 2 + 2 * Hkv * D * 2
     timed("decode_attn_split_kernel+decode_attn_combine_kernel", NL, NL * n_dec, attn_bytes, 4.0 * (L + 1) * Hq * D,
           lambda: [o.decode_attn(eng.d_qkv[:qd], c.pool, i, c.slot_of_dev, eng.rope_cs, eng.d_attn, eng.d_ws, Hq, eng._attn_len,
-                                 eng.decode_chunk, scale, length=1, len_dev=kv_dev) for i in range(NL)])
+                                 eng.decode_chunk, scale, length=1, len_dev=kv_dev, lin=lin) for i in range(NL)])
     timed("gemv_bf16_kernel(o_proj)", NL, NL * n_dec, 2 * (H * qd + qd + 2 * H), 2.0 * H * qd,
           lambda: [o.gemv(eng.d_attn, l["o_w"], residual=eng.d_x, out=eng.d_x) for l in lw])
     timed("dec_gate_up_kernel", NL, NL * n_dec, 2 * (2 * I * H + 2 * H + I), 4.0 * I * H,
@@ -537,13 +541,17 @@ def roofline_pass(model, args, kv_len):
         cap = Lbig + 64
         slot = torch.arange(cap, dtype=torch.int32, device=dev)
         rope = torch.randn((cap, D), device=dev).to(torch.bfloat16)
-        ch = type(eng).pick_decode_chunk(cap, hkv)
+        ch = type(eng).pick_decode_chunk(cap, hkv, eng.linear_planes)
         ws = o.decode_attn_ws(hq, cap, ch, dev)
         out = torch.empty(hq * D, dtype=torch.bfloat16, device=dev)
         qq = torch.randn(hq * D, device=dev).to(torch.bfloat16)
         n_pools = max(8, -(-(640 << 20) // (2 * hkv * cap * D * 2)))     # >= 640 MB of distinct K/V per replay: 2.5x the Infinity Cache
         pools = [(torch.randn((1, 2, hkv, cap, D), device=dev) * 0.5).to(torch.bfloat16) for _ in range(n_pools)]
-        fn = lambda: [o.decode_attn(qq, p, 0, slot, rope, out, ws, hq, cap, ch, scale, length=Lbig) for p in pools]
+        # as the engine runs it: the cache's linear planes hold the prefill's rotated keys / values of all rows but the ones decoded since
+        lin_rows = -(-cap // 16) * 16
+        lins = [((torch.randn((1, 2, hkv, lin_rows, D), device=dev) * 0.5).to(torch.bfloat16),
+                 torch.tensor([Lbig - 16], dtype=torch.int32, device=dev)) if eng.linear_planes else None for _ in range(n_pools)]
+        fn = lambda: [o.decode_attn(qq, p, 0, slot, rope, out, ws, hq, cap, ch, scale, length=Lbig, lin=ln) for p, ln in zip(pools, lins)]
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -563,7 +571,7 @@ def roofline_pass(model, args, kv_len):
         nb = 2 * Lbig * hkv * D * 2 + Lbig * 3 * 4
         return {"kv_len": Lbig, "q_heads": hq, "kv_heads": hkv, "keys_per_workgroup": ch, "avg_launch_us": round(best * 1e3, 2),
                 "achieved": round(nb / best / 1e6, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": round(nb / best / 1e6 / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_launch": nb}
+                "algorithmic_bytes_per_launch": nb, "linear_planes": bool(eng.linear_planes)}
     try:
         extra["roofline_decode_attn_32k"] = long_point(Hq, Hkv, 32768)
         pts = [long_point(Hq, Hkv, 131072)]

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   if (start >= L) return;
   const int n_rows = min(chunk, L - start);
   const int n_steps = (n_rows + 15) >> 4;        // workgroup-uniform
-  const bf16_t* csq = rope_cs + (size_t)(L - 1) * DA_D;
+  const bf16_t* csq = rope_cs + (size_t)(L - 1) * DA_D;      // (behind the length, but not on the critical path: measured with row 0 instead)
   const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + fc);
   const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + fc);
   // a key range that lies inside the valid part of the linear planes keeps the rows requested above; any other (the range that holds
@@ -470,6 +470,21 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D;
   const bf16_t* vp = v_planes + (size_t)kvh * n_slots * DA_D;
 
+  // linear planes: the 16-key tile r of kv head h is 4 KB at k_lin + (h * lin_rows / 16 + r) * 2048, laid out as the four operand loads
+  // of this kernel: [ks][lane][8] (lane = fq * 16 + key) -- every load instruction reads 1 KB of consecutive bytes; V rows are row-major
+  auto load_lin = [&](int t, DaTile& b) {
+    const int rt = min((start >> 4) + t * 4 + wave, (lin_rows >> 4) - 1);      // (clamped: the first tile is requested before the lengths are known)
+    const bf16_t* kt = k_lin + ((size_t)kvh * (lin_rows >> 4) + rt) * 2048 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b.k[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kt + ks * 512));
+    const bf16_t* vt = v_lin + ((size_t)kvh * lin_rows + rt * 16 + fq) * DA_D + fr * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vt + (size_t)i * 4 * DA_D));
+  };
+  DaTile A, B;
+  // WLIN: the wave's first tile is requested NOW -- the planes are allocated to lin_rows, whether the rows are valid is decided below --
+  // so the query staging (two dependent loads, a rotation, a barrier: ~1.5 us) runs underneath the first K/V bytes
+  if constexpr (WLIN) load_lin(0, A);
   // rotated query block -> Qs (rows >= G are zero), exactly as the kernels above
   {
     const int srow = tid >> 4, c = tid & 15;
@@ -492,29 +507,21 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     *reinterpret_cast<u32x4_t*>(Qs + srow * DA_KLD + c * 8) = outq;
   }
   const int L = (len_dev ? *len_dev : 0) + len_add;
-  if (start >= L) return;                                   // workgroup-uniform
+  if (start >= L) {                                         // workgroup-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the requested tile must have landed before the wave's registers are released)
+    return;
+  }
   const int n_rows = min(chunk, L - start);
   const int n_tiles = (n_rows + 15) >> 4;                   // of the workgroup; wave w owns tiles w, w + 4, ...
   // WLIN: rows [0, lin_len) of the cache also exist ROTATED, in logical order, in the linear planes the prefill left behind (header of
   // svlm_decode_attn_lin): tiles that lie there are streamed from them (no slot table, no cos/sin rows, no rotation).  Without
   // linear planes (!WLIN) the kernel is the pipelined pool path alone.
   const int lin_len = WLIN ? min(*lin_len_dev, L) : 0;
-  __syncthreads();                                          // Qs visible
+  lds_barrier();                                            // Qs visible (LDS only: the tile requested above stays in flight)
   bf16x8_t qf[4];                                           // this lane's B fragments of the query block: constant over the loop
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(Qs + fr * DA_KLD + ks * 32 + fq * 8);
 
-  // linear planes: the 16-key tile r of kv head h is 4 KB at k_lin + (h * lin_rows / 16 + r) * 2048, laid out as the four operand loads
-  // of this kernel: [ks][lane][8] (lane = fq * 16 + key) -- every load instruction reads 1 KB of consecutive bytes; V rows are row-major
-  auto load_lin = [&](int t, DaTile& b) {
-    const int r0 = start + (t * 4 + wave) * 16;
-    const bf16_t* kt = k_lin + ((size_t)kvh * (lin_rows >> 4) + (r0 >> 4)) * 2048 + lane * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b.k[ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kt + ks * 512));
-    const bf16_t* vt = v_lin + ((size_t)kvh * lin_rows + r0 + fq) * DA_D + fr * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) b.v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vt + (size_t)i * 4 * DA_D));
-  };
   auto load_tile = [&](int t, int slot_own, DaTile& b) {
     // K in operand layout: piece ks of row `slot_own`; cos / sin pieces of the key's logical row
     const bf16_t* krow = kp + (size_t)slot_own * DA_D + fq * 8;
@@ -626,12 +633,10 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
 
   // software pipeline, two named tile buffers; a wave's tile index runs 0 .. nt - 1 (workgroup tile 4 t + wave)
   const int nt = n_tiles > wave ? (n_tiles - wave + 3) >> 2 : 0;   // tiles of this wave
-  DaTile A, B;
   if constexpr (WLIN) {
     // the wave's tiles that lie wholly below lin_len (a prefix of them: all but the one or two that hold the rows appended since the
-    // prefill) are streamed from the linear planes, pipelined; the rest come from the pool, one at a time
+    // prefill) are streamed from the linear planes, pipelined (tile 0 is already on its way); the rest come from the pool, one at a time
     const int ntl = min(nt, max(0, ((lin_len - start) >> 4) - wave + 3) >> 2);
-    if (ntl > 0) load_lin(0, A);
 #pragma unroll
     for (int t = 0; t < DA_STREAM_TPW; t += 2) {
       if (t >= ntl) break;                                  // wave-uniform

@@ -279,7 +279,7 @@ class SvlmEngine:
         # CURRENT sequence length -- an engine sized for a 90k-row dense prefill decodes its 4k-row live window with the
         # bounded-window geometry, not with the long-cache one
         self._fixed_chunk = decode_chunk if decode_chunk is not None else (int(os.environ["SVLM_DECODE_CHUNK"]) if "SVLM_DECODE_CHUNK" in os.environ else None)
-        self.decode_chunk = int(self._fixed_chunk if self._fixed_chunk is not None else self.pick_decode_chunk(self.max_len, tc.num_kv_heads))
+        self.decode_chunk = int(self._fixed_chunk if self._fixed_chunk is not None else self.pick_decode_chunk(self.max_len, tc.num_kv_heads, self.linear_planes))
         self._attn_len = self.max_len          # bound on the sequence length the current call's decode attention covers
         self.use_graph = (os.environ.get("SVLM_NO_GRAPH", "0") != "1") if use_graph is None else bool(use_graph)
         dev = self.device
@@ -352,7 +352,7 @@ class SvlmEngine:
         self._sample_calls = 0
 
     @staticmethod
-    def pick_decode_chunk(max_len: int, n_kv_heads: int) -> int:
+    def pick_decode_chunk(max_len: int, n_kv_heads: int, linear_planes: bool = True) -> int:
         """Keys per decode-attention workgroup (measured on MI355X, tools/decode_attn_sweep.py): 48 at the bounded windows
         of the streaming configs (2B @ 2048: 8.5 us, 7B @ 4096: 12.3 us; fewer, fatter splits starve the chip, more of them
         bloat the combine).  Long caches run the barrier-free streaming kernel (chunk > 64): 128 keys while the cache is small
@@ -363,6 +363,11 @@ class SvlmEngine:
         if max_len <= 6144:
             return 48
         hk = max_len * n_kv_heads
+        if linear_planes:
+            # streaming from the linear planes (no cos/sin rows, no rotation: each workgroup is done sooner, fewer and fatter ones pay):
+            # 2 kv heads x 8k 128: 10.0 us; x 32k 192: 15.1 (128: 16.3); 4 x 32k 320-384: 19.7 (192: 21.2); 2 x 131k 512: 29.4 (256: 33.4);
+            # 4 x 131k 512: 52.1 (384: 56.7)
+            return 128 if hk < 40_000 else (192 if hk < 100_000 else (384 if hk < 200_000 else 512))
         return 128 if hk < 100_000 else (192 if hk < 400_000 else 512)
 
     # ------------------------------------------------------------------ cache
@@ -670,7 +675,7 @@ class SvlmEngine:
             need = L_ids + max_new_tokens
             step = 1024 if need <= 8192 else 8192
             self._attn_len = min(self.max_len, -(-need // step) * step)
-            self.decode_chunk = self.pick_decode_chunk(self._attn_len, tc.num_kv_heads)
+            self.decode_chunk = self.pick_decode_chunk(self._attn_len, tc.num_kv_heads, self.linear_planes)
         # ---- shrink-mode positions for the whole (pruned) sequence + the tokens to be generated
         n_rows = L_ids + max_new_tokens
         is_f = cfg.family == "qwen2_5" and not all_text

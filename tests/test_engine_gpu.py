@@ -208,6 +208,24 @@ def test_graph_replay_equals_eager_launches():
             assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("family", ["qwen2", "qwen2_5"])
+def test_decode_steps_on_the_prefills_rotated_keys_equal_rotation_at_every_step(family):
+    """The engine's decode attention streams the rotated keys the chunk's prefill left in the cache's linear planes and takes only the
+    rows decoded since from the pool (kv_pool.py); an engine without the planes rotates every pool row at every step, as the reference
+    does (language_forward.py:55-63).  Same bits: ids and every forward's logits, over chunks with eviction in between."""
+    import streaming_vlm_amd as S
+    cfg, sd, _ = _tiny_model(family=family)
+    logs = []
+    for lp in (True, False):
+        model = S.StreamingQwen2VL(cfg, {k: v.cuda() for k, v in sd.items()}, "cuda", max_len=768, max_new_tokens=8, linear_planes=lp)
+        assert model._svlm_engine.linear_planes is lp and (model._svlm_engine.new_cache().lin is not None) is lp
+        logs.append(H.run_engine_stream(model, 6, keep_logits=True)[3])
+    for a, b in zip(*logs):
+        assert a["ids"] == b["ids"]
+        for x, y in zip(a["logits"], b["logits"]):
+            assert torch.equal(x, y)
+
+
 def test_two_streams_alternating_on_one_engine_keep_their_graphs():
     """Two KV pools taking turns on one engine (two streams sharing a model replica): each pool's decode graph is captured once and
     found again by the pool's serial -- the engine holds the pool while it holds the graph -- and both streams produce what they

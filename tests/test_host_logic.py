@@ -227,6 +227,49 @@ def test_pool_position_history_follows_prune_and_move():
     assert _rows(pool)[0] == ref                        # the K rows moved the same way
 
 
+def test_linear_planes_validity_follows_every_edit_of_the_logical_order():
+    """KVPool.lin_valid / *lin_len_dev: what the decode kernels may stream from the prefill's rotated copy (kv_pool.py).  A prefill
+    raises it to its length; prune / move / truncate / plane assignment / update() lower it to the first row they disturb; appends
+    (reserve / commit / release_reserved) and defragmentation (slots move, logical rows do not) leave it; the device copy follows at
+    the next sync_device()."""
+    pool = _pool(max_len=256, pages=16)
+    pool.slot_of_dev = torch.from_numpy(pool.slot_of)
+    assert pool.lin is not None and pool.lin.shape == (2, 2, 2, 256, 128) and pool.lin_args()[1] is pool.lin_len_dev
+    _fill(pool, 200, 0)
+    pool.lin_written(200); pool.lin_len_dev.fill_(200)           # what the gather launches of a prefill do
+    pool.reserve(20); pool.commit(210); pool.release_reserved()  # decode steps: appended rows, unused tail given back
+    pool.sync_device()
+    assert pool.lin_valid == 200 and int(pool.lin_len_dev[0]) == 200
+    pool.move(150, 160, 99)
+    assert pool.lin_valid == 100 and int(pool.lin_len_dev[0]) == 200          # host first ...
+    pool.sync_device()
+    assert int(pool.lin_len_dev[0]) == 100                                     # ... the device at the next sync
+    pool.prune(120, 130)
+    assert pool.lin_valid == 100
+    pool.prune(40, 50)
+    assert pool.lin_valid == 40
+    pool.defragment()
+    assert pool.lin_valid == 40
+    pool.truncate(30); pool.sync_device()
+    assert pool.lin_valid == 30 and int(pool.lin_len_dev[0]) == 30
+    pool.lin_written(30)
+    g = torch.Generator().manual_seed(1)
+    k, v = (torch.randn(1, 2, 7, 128, generator=g).to(torch.bfloat16) for _ in range(2))
+    for layer in range(2):
+        pool.update(k, v, layer)                                 # rows that exist in the pool only
+    assert pool.lin_valid == 30 and pool.get_seq_length() == 37
+    pool.lin_written(37)
+    for i, (kk, vv) in enumerate(list(pool)):
+        pool.key_cache[i] = kk[:, :, :20]
+        pool.value_cache[i] = vv[:, :, :20]
+    pool.sync_device()
+    assert pool.lin_valid == 0 and int(pool.lin_len_dev[0]) == 0
+    bare = S.KVPool(2, 2, 128, 64, "cpu", RefOps(), linear_planes=False)
+    assert bare.lin is None and bare.lin_args() is None
+    bare.lin_written(10)
+    assert bare.lin_valid == 0
+
+
 def test_pool_prune_move_truncate_match_list_semantics():
     pool = _pool()
     pool.slot_of_dev = torch.from_numpy(pool.slot_of)      # CPU "device" mirror shares memory

@@ -16,9 +16,9 @@ jobs = []
 for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
     obj = os.path.join(OUT, "diag", os.path.basename(src)[:-4] + ".o")
     objs.append(obj)
-    jobs.append([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DSVLM_TUNING", "-c", src, "-o", obj])
+    jobs.append([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-DSVLM_TUNING"] + os.environ.get("SVLM_DIAG_DEFS", "").split() + ["-c", src, "-o", obj])
 with ThreadPoolExecutor(max_workers=4) as ex:
     list(ex.map(lambda j: subprocess.check_call(j, cwd=CSRC), jobs))
-lib = os.path.join(OUT, "libsvlm_hip_diag.so")
+lib = os.path.join(OUT, os.environ.get("SVLM_DIAG_NAME", "libsvlm_hip_diag.so"))
 subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, cwd=CSRC)
 print(lib)
