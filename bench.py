@@ -390,7 +390,7 @@ def roofline_pass(model, args, kv_len):
     lin = c.lin_args()
     if lin is not None:                  # the decode step in the MIDDLE of a chunk: the prefill's rotated copy covers all but the rows decoded since
         c.lin.normal_()
-        c.lin_len_dev.fill_(max(L - (args.new_tokens - 1) // 2, 0))
+        c.lin_len_dev.copy_(torch.tensor([max(L - (args.new_tokens - 1) // 2, 0), 1], dtype=torch.int32))
     pos = torch.arange(L + 1, dtype=torch.int32, device=dev).repeat(3, 1)
     eng.pos3_dev[:, :L + 1].copy_(pos)
     o.mrope_table(eng.pos3_dev, eng.inv_freq, eng.rope_cs, 0, L + 1, tc.mrope_section)
@@ -550,7 +550,7 @@ def roofline_pass(model, args, kv_len):
         # as the engine runs it: the cache's linear planes hold the prefill's rotated keys / values of all rows but the ones decoded since
         lin_rows = -(-cap // 16) * 16
         lins = [((torch.randn((1, 2, hkv, lin_rows, D), device=dev) * 0.5).to(torch.bfloat16),
-                 torch.tensor([Lbig - 16], dtype=torch.int32, device=dev)) if eng.linear_planes else None for _ in range(n_pools)]
+                 torch.tensor([Lbig - 16, 1], dtype=torch.int32, device=dev)) if eng.linear_planes else None for _ in range(n_pools)]
         fn = lambda: [o.decode_attn(qq, p, 0, slot, rope, out, ws, hq, cap, ch, scale, length=Lbig, lin=ln) for p, ln in zip(pools, lins)]
         fn()
         torch.cuda.synchronize()

@@ -187,9 +187,11 @@ int svlm_decode_attn_ropeload(const void* q, const void* k_planes, const void* v
  *   k_lin (Hkv, lin_rows/16, 4, 64, 8) bf16  16-key tiles of ROTATED keys in logical order; inside a tile chunk c (8 values) of key r
  *                                            sits at [c >> 2][(c & 3) * 16 + r][8], the operand layout of the decode kernels
  *   v_lin (Hkv, lin_rows, 128) bf16          values in logical order
- *   *lin_len_dev                             rows [0, *lin_len_dev) of both are valid; key ranges above it (the rows appended since
- *                                            the prefill) are read from the pool and rotated as svlm_decode_attn_ropeload does
- * lin_rows % 16 == 0, lin_rows >= max_len; all three NULL = svlm_decode_attn_ropeload.  Same bits either way. */
+ *   lin_len_dev[2] = {R, F}                  rows [0, R) of both are valid with ROTATED keys; F != 0: the rows appended since the
+ *                                            prefill follow at their logical rows with UN-rotated keys (svlm_dec_qkv_lin) and are
+ *                                            rotated while they are staged; F == 0: rows >= R come from the pool as in
+ *                                            svlm_decode_attn_ropeload
+ * lin_rows % 16 == 0, lin_rows >= max_len; all three NULL = svlm_decode_attn_ropeload.  Same bits every way. */
 int svlm_decode_attn_lin(const void* q, const void* k_planes, const void* v_planes, const int* slot_of, const void* rope_cs,
                          const int* len_dev, int len_add, const void* k_lin, const void* v_lin, int lin_rows, const int* lin_len_dev,
                          void* out, void* ws, int Hq, int Hkv, int D, int n_slots, int max_len, int chunk, float scale, void* stream);
@@ -206,7 +208,7 @@ int svlm_prefill_attn_ropeload(const void* q, int q_stride, const void* k_new, c
                                void* k_planes, void* v_planes, const int* slot_of, const void* rope_cs, void* out, int o_stride,
                                int T, int L, int Hq, int Hkv, int D, int n_slots, float scale, void* ws, long long ws_bytes,
                                void* stream);
-/* ... which also leaves rows [0, L) of the layer's linear planes (svlm_decode_attn_lin) behind and sets *lin_len_dev = L
+/* ... which also leaves rows [0, L) of the layer's linear planes (svlm_decode_attn_lin) behind and sets lin_len_dev[0..1] = {L, 1}
  * (k_lin, v_lin, lin_len_dev together or all NULL; lin_rows % 16 == 0, lin_rows >= L). */
 int svlm_prefill_attn_ropeload_lin(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
                                    void* k_planes, void* v_planes, const int* slot_of, const void* rope_cs, void* out, int o_stride,
@@ -239,6 +241,11 @@ int svlm_penalty_sample(const float* logits, int V, void* seen, float penalty, c
 int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out, void* k_planes,
                  void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd, int kd, int D, int n_slots,
                  void* stream);
+/* ... and ALSO into the layer's linear planes (svlm_decode_attn_lin) at logical row *len_dev or len_host: V as it is, K un-rotated
+ * in its tile position (k_lin, v_lin together or both NULL; the row must be below lin_rows). */
+int svlm_dec_qkv_lin(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out, void* k_planes,
+                     void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd, int kd, int D, int n_slots,
+                     void* k_lin, void* v_lin, int lin_rows, void* stream);
 /* RMSNorm(x; ln_w) -> h[n] = silu(Wg[n] x) * (Wu[n] x), W = [gate(I) | up(I)] rows.  replaces: :200-201 (Qwen2MLP). */
 int svlm_dec_gate_up(const void* x, const void* ln_w, float eps, const void* W, int ldw, void* h, int I, int K, void* stream);
 

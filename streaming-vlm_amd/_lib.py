@@ -64,6 +64,7 @@ SIGNATURES = {
     "svlm_penalty_sample": (_i, [_p, _i, _p, _f, _p, _i, _f, _i, _f, _p, _p, _p, _i, _p, _p]),
     "svlm_dec_lm_head_sample": (_i, [_p, _p, _f, _p, _i, _p, _p, _f, _p, _i, _p, _i, _i, _f, _p, _p, _p]),
     "svlm_dec_qkv": (_i, [_p, _p, _f, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "svlm_dec_qkv_lin": (_i, [_p, _p, _f, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "svlm_dec_gate_up": (_i, [_p, _p, _f, _p, _i, _p, _i, _i, _p]),
     "svlm_dec_tail_supported": (_i, [_i, _i, _i, _i, _i]),
     "svlm_dec_tail_ws_bytes": (_ll, [_i, _i, _i]),

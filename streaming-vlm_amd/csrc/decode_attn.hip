@@ -48,6 +48,20 @@ typedef short v4s_da_t __attribute__((ext_vector_type(4)));
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u(unsigned v) { return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xF, 0xF, true); }
 
+// Diagnostic build only (tools/decode_attn_stamps.py): wall-clock stamps of the phases of the bounded-window pair, 8 per workgroup
+#ifdef SVLM_TUNING
+__device__ unsigned long long* da_stamps = nullptr;
+extern "C" int svlm_diag_set_da_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(da_stamps), &p, sizeof(p)) == hipSuccess ? SVLM_OK : SVLM_ELAUNCH;
+}
+#define DA_STAMP(wg, i)                                                                        \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && da_stamps != nullptr) da_stamps[(size_t)(wg) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define DA_STAMP(wg, i) do { } while (0)
+#endif
+
 template <int G>
 __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_planes, const bf16_t* __restrict__ v_planes,
@@ -67,6 +81,9 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   const int kvh = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int srow = tid >> 4, c = tid & 15;      // staging: 16 lanes per 256-B row
+  const int wg_id = blockIdx.y * gridDim.x + blockIdx.x;
+  (void)wg_id;
+  DA_STAMP(wg_id, 0);
   const bool upper = c >= 8;
   const int fc = (c & 7) * 8;
   const bf16_t* kp = k_planes + (size_t)kvh * n_slots * DA_D + c * 8;
@@ -98,16 +115,37 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   }
   const int L = (len_dev ? *len_dev : 0) + len_add;
   if (start >= L) return;
+  DA_STAMP(wg_id, 1);
   const int n_rows = min(chunk, L - start);
   const int n_steps = (n_rows + 15) >> 4;        // workgroup-uniform
   const bf16_t* csq = rope_cs + (size_t)(L - 1) * DA_D;      // (behind the length, but not on the critical path: measured with row 0 instead)
   const u32x4_t qc = *reinterpret_cast<const u32x4_t*>(csq + fc);
   const u32x4_t qs = *reinterpret_cast<const u32x4_t*>(csq + 64 + fc);
-  // a key range that lies inside the valid part of the linear planes keeps the rows requested above; any other (the range that holds
-  // the rows appended since the prefill) takes them from the pool and rotates them
-  const int lin_len = (k_lin != nullptr && lin_len_dev != nullptr) ? min(*lin_len_dev, L) : 0;
-  const bool wg_lin = start + chunk <= lin_len;             // workgroup-uniform; implies n_rows == chunk
-  if (!wg_lin) {
+  // lin_state = {rows rotated, fresh rows present}: rows below lin_state[0] are rotated in the linear planes; with lin_state[1] the rows
+  // above it (appended by svlm_dec_qkv_lin since the prefill) are there too, UN-rotated.  A key range wholly below lin_state[0] keeps the
+  // rows requested above as they are (wg_lin); the range that holds appended rows keeps them and rotates those (wg_fresh: their cos /
+  // sin rows are requested only now, behind the length, but they are a few rows of a table every layer reads); without the fresh rows
+  // (a host edit of the logical order since the prefill, a decode step that does not maintain the planes) it takes the pool path
+  int lin_rot = 0;
+  bool lin_fresh = false;
+  if (k_lin != nullptr && lin_len_dev != nullptr) {
+    lin_rot = min(lin_len_dev[0], L);
+    lin_fresh = lin_len_dev[1] != 0;
+  }
+  const bool wg_lin = start + chunk <= lin_rot;             // workgroup-uniform; implies n_rows == chunk
+  const bool wg_fresh = !wg_lin && lin_fresh;               // workgroup-uniform
+  if (wg_fresh) {
+#pragma unroll
+    for (int it = 0; it < DA_MAX_STEPS; ++it) {
+      if (it >= n_steps) break;
+      craw[it] = sraw[it] = u32x4_t{0, 0, 0, 0};
+      if (start + it * 16 + srow >= lin_rot) {
+        const bf16_t* csr = rope_cs + (size_t)rows[it] * DA_D;
+        craw[it] = *reinterpret_cast<const u32x4_t*>(csr + fc);
+        sraw[it] = *reinterpret_cast<const u32x4_t*>(csr + 64 + fc);
+      }
+    }
+  } else if (!wg_lin) {
 #pragma unroll
     for (int it = 0; it < DA_MAX_STEPS; ++it) {
       if (it >= n_steps) break;
@@ -154,11 +192,14 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     unpack8(kraw[it], x); unpack8(kp4, xp); unpack8(craw[it], cc); unpack8(sraw[it], sn);
     rope8(x, xp, cc, sn, upper, o);
     const bool ok = lrow < n_rows;
+    const bool rotated = wg_fresh && start + lrow < lin_rot;        // (this row came rotated; its cos / sin registers hold nothing)
     const u32x4_t z = u32x4_t{0, 0, 0, 0};
-    *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = ok ? pack8(o) : z;
+    *reinterpret_cast<u32x4_t*>(Ks + lrow * DA_KLD + c * 8) = ok ? (rotated ? kraw[it] : pack8(o)) : z;
     *reinterpret_cast<u32x4_t*>(Vs + lrow * DA_VLD + c * 8) = ok ? vraw[it] : z;
   }
+  DA_STAMP(wg_id, 2);
   __syncthreads();
+  DA_STAMP(wg_id, 3);
 
   // ---- wave w: 16-key tile w
   const int fr = lane & 15, fq = lane >> 4;
@@ -200,6 +241,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
       oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb, oacc[dt], 0, 0, 0);
     }
   }
+  DA_STAMP(wg_id, 4);
   __syncthreads();          // every wave is done with Ks / Vs: the region becomes the merge buffer
   if (fr < G) {
 #pragma unroll
@@ -207,6 +249,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
   }
   __syncthreads();
+  DA_STAMP(wg_id, 5);
   const size_t part = (size_t)blockIdx.x * Hq;
   for (int idx = tid; idx < G * DA_D; idx += 256) {
     const int g = idx / DA_D, d = idx % DA_D;
@@ -224,6 +267,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     ws_acc[(part + hq) * DA_D + d] = a;
     if (d == 0) { ws_m[part + hq] = mn; ws_l[part + hq] = l; }
   }
+  DA_STAMP(wg_id, 6);
 }
 
 // One workgroup per q head; wave w merges splits w, w+4, ... with 4 loads in flight per lane, then the
@@ -516,7 +560,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   // WLIN: rows [0, lin_len) of the cache also exist ROTATED, in logical order, in the linear planes the prefill left behind (header of
   // svlm_decode_attn_lin): tiles that lie there are streamed from them (no slot table, no cos/sin rows, no rotation).  Without
   // linear planes (!WLIN) the kernel is the pipelined pool path alone.
-  const int lin_len = WLIN ? min(*lin_len_dev, L) : 0;
+  const int lin_len = WLIN ? min(lin_len_dev[0], L) : 0;
+  const bool lin_fresh = WLIN ? lin_len_dev[1] != 0 : false;        // rows above lin_len are in the planes too, un-rotated (svlm_dec_qkv_lin)
   lds_barrier();                                            // Qs visible (LDS only: the tile requested above stays in flight)
   bf16x8_t qf[4];                                           // this lane's B fragments of the query block: constant over the loop
 #pragma unroll
@@ -550,8 +595,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt) oacc[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](auto lin_c, int t, const DaTile& b) {
-    constexpr bool LIN = decltype(lin_c)::value;            // keys already rotated (linear planes)
+  auto compute = [&](auto mode_c, int t, const DaTile& b) {
+    constexpr int MODE = decltype(mode_c)::value;           // 0: rotate every key (pool rows); 1: keys come rotated (linear planes);
+    constexpr bool LIN = MODE == 1;                         // 2: linear planes, keys at or above lin_len are rotated here
     const int base = (t * 4 + wave) * 16;                   // first key of the tile, relative to `start`
     if constexpr ((DIAG & 2) != 0) {                        // timing only: every loaded register is consumed, nothing else happens
       unsigned x = 0;
@@ -581,6 +627,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
           ou[i] = rbf(rbf(xu[i] * cc[i]) + rbf(xl[i] * sn[i]));
         }
         u32x4_t pl = pack8(ol), pu = pack8(ou);
+        if constexpr (MODE == 2) {                          // this lane's key (row base + fr) came rotated
+          if (start + base + fr < lin_len) { pl = b.k[h]; pu = b.k[h + 2]; }
+        }
         kf[h] = *reinterpret_cast<bf16x8_t*>(&pl);
         kf[h + 2] = *reinterpret_cast<bf16x8_t*>(&pu);
       }
@@ -635,23 +684,31 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   const int nt = n_tiles > wave ? (n_tiles - wave + 3) >> 2 : 0;   // tiles of this wave
   if constexpr (WLIN) {
     // the wave's tiles that lie wholly below lin_len (a prefix of them: all but the one or two that hold the rows appended since the
-    // prefill) are streamed from the linear planes, pipelined (tile 0 is already on its way); the rest come from the pool, one at a time
+    // prefill) are streamed from the linear planes, pipelined (tile 0 is already on its way); the rest one at a time
     const int ntl = min(nt, max(0, ((lin_len - start) >> 4) - wave + 3) >> 2);
 #pragma unroll
     for (int t = 0; t < DA_STREAM_TPW; t += 2) {
       if (t >= ntl) break;                                  // wave-uniform
       if (t + 1 < DA_STREAM_TPW) load_lin(min(t + 1, ntl - 1), B);      // redundant reload at the end: harmless
       __builtin_amdgcn_sched_barrier(0);
-      compute(std::true_type{}, t, A);
+      compute(std::integral_constant<int, 1>{}, t, A);
       if (t + 1 >= ntl) break;
       if (t + 2 < DA_STREAM_TPW) load_lin(min(t + 2, ntl - 1), A);
       __builtin_amdgcn_sched_barrier(0);
-      compute(std::true_type{}, t + 1, B);
+      compute(std::integral_constant<int, 1>{}, t + 1, B);
     }
     for (int t = ntl; t < nt; ++t) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // a trailing redundant load of the loop above may still be writing A
-      load_tile(t, slot_of[min(start + (t * 4 + wave) * 16 + fr, max_len - 1)], A);
-      compute(std::false_type{}, t, A);
+      if (lin_fresh) {                                      // (kernel-uniform) the appended rows are in the planes: rotate them here
+        load_lin(t, A);
+        const bf16_t* csr = rope_cs + (size_t)min(start + (t * 4 + wave) * 16 + fr, max_len - 1) * DA_D + fq * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A.cs[i] = *reinterpret_cast<const u32x4_t*>(csr + i * 32);
+        compute(std::integral_constant<int, 2>{}, t, A);
+      } else {                                              // planes not maintained since the prefill: pool rows
+        load_tile(t, slot_of[min(start + (t * 4 + wave) * 16 + fr, max_len - 1)], A);
+        compute(std::integral_constant<int, 0>{}, t, A);
+      }
     }
   } else {
     // slot of key (lane & 15) in each of the wave's tiles (stale / clamped entries are valid slots; masked later)
@@ -664,11 +721,11 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
       if (t >= nt) break;                                   // wave-uniform
       if (t + 1 < DA_STREAM_TPW) load_tile(min(t + 1, nt - 1), slot_t[t + 1 < DA_STREAM_TPW ? t + 1 : t], B);      // redundant reload at the end: harmless
       __builtin_amdgcn_sched_barrier(0);
-      compute(std::false_type{}, t, A);
+      compute(std::integral_constant<int, 0>{}, t, A);
       if (t + 1 >= nt) break;
       if (t + 2 < DA_STREAM_TPW) load_tile(min(t + 2, nt - 1), slot_t[t + 2 < DA_STREAM_TPW ? t + 2 : t], A);
       __builtin_amdgcn_sched_barrier(0);
-      compute(std::false_type{}, t + 1, B);
+      compute(std::integral_constant<int, 0>{}, t + 1, B);
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // trailing redundant loads must not outlive the registers
@@ -714,6 +771,9 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
   const int hq = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cl = lane % CW, sub = lane / CW;
+  const int cwg = 4096 + blockIdx.y * gridDim.x + blockIdx.x;      // (stamp rows of the combine sit behind the split's)
+  (void)cwg;
+  DA_STAMP(cwg, 0);
   const int col = blockIdx.y * (DA_D / DS) + 2 * cl;
   const int first = wave * SUB + sub;
   // The first batch does not wait for the length: slots beyond the live splits are valid memory of the workspace (clamped to
@@ -775,7 +835,9 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
     sa[wave][2 * cl] = a0;
     sa[wave][2 * cl + 1] = a1;
   }
+  DA_STAMP(cwg, 1);
   __syncthreads();
+  DA_STAMP(cwg, 2);
   if (threadIdx.x < DA_D / DS) {
     const int d = threadIdx.x;
     float mt = sm[0];
@@ -790,6 +852,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const floa
     }
     out[(size_t)hq * DA_D + blockIdx.y * (DA_D / DS) + d] = f2bf(at / lt);
   }
+  DA_STAMP(cwg, 3);
 }
 
 // ws layout: [max_splits*Hq] m | [max_splits*Hq] l | [max_splits*Hq*128] acc   (floats)
@@ -853,10 +916,11 @@ static void launch_split(dim3 grid, hipStream_t st, const bf16_t* q, const bf16_
 //   k_lin  (Hkv, lin_rows / 16, 4, 64, 8) bf16: 16-key tiles of ROTATED keys in logical order, each tile laid out as the four MFMA
 //          operand loads of the decode kernels ([ks][lane = fq * 16 + key][8]: one load instruction = 1 KB of consecutive bytes)
 //   v_lin  (Hkv, lin_rows, 128) bf16: values in logical order
-//   *lin_len_dev: rows [0, *lin_len_dev) of both are valid (written by the prefill; the host lowers it when it edits the logical order)
-// A workgroup whose whole key range lies below *lin_len_dev reads no slot table, no cos / sin rows and rotates nothing; any other (the
-// range with the rows appended since the prefill: at most max_new_tokens of them) takes the pool path.  Same bits either way: the
-// rotation arithmetic of the two producers is the same expression.
+//   lin_len_dev[2] = {R, F}: rows [0, R) of both are valid, keys ROTATED (written by the prefill; the host lowers R when it edits the
+//          logical order); F != 0: the rows appended since (svlm_dec_qkv_lin writes them) follow at their logical rows, keys UN-rotated
+// A key range below R needs no slot table, no cos / sin rows and no rotation; the range with the appended rows (at most max_new_tokens
+// of them) rotates those while it stages them -- or, with F == 0 (a host edit since the prefill, a decode step that does not maintain
+// the planes), takes the pool path.  Same bits every way: the rotation arithmetic of all producers is the same expression.
 extern "C" int svlm_decode_attn_lin(const void* q, const void* k_planes, const void* v_planes, const int* slot_of,
                                     const void* rope_cs, const int* len_dev, int len_add, const void* k_lin, const void* v_lin,
                                     int lin_rows, const int* lin_len_dev, void* out, void* ws,

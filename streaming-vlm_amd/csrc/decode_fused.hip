@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__
                                                       bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_planes,
                                                       bf16_t* __restrict__ v_planes, const int* __restrict__ slot_of,
                                                       const int* __restrict__ len_dev, int len_host, int N, int K, int qd, int kd,
-                                                      int D, int n_slots) {
+                                                      int D, int n_slots, bf16_t* __restrict__ k_lin, bf16_t* __restrict__ v_lin,
+                                                      int lin_rows) {
   bf16_t* xs = reinterpret_cast<bf16_t*>(dyn_smem);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n0 = (blockIdx.x * 4 + wave) * ROWS;
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__
   __builtin_amdgcn_sched_barrier(0);
   WPre<ROWS, PRE> pre;
   preload_w<ROWS, PRE>(wr, 0, K, pre);
-  const int slot = slot_of[len_dev ? *len_dev : len_host];
+  const int row = len_dev ? *len_dev : len_host;
+  const int slot = slot_of[row];
   bf16_t bpre[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) bpre[r] = bias[min(n0 + r, N - 1)];
@@ -168,6 +170,13 @@ __global__ __launch_bounds__(256) void dec_qkv_kernel(const bf16_t* __restrict__
         const int jj = j < kd ? j : j - kd;
         bf16_t* plane = j < kd ? k_planes : v_planes;
         plane[((size_t)(jj / D) * n_slots + slot) * D + jj % D] = v;
+        if (k_lin != nullptr) {
+          // ... and into the cache's linear planes at logical row `row` (svlm_decode_attn_lin): the value as it is, the key UN-rotated in
+          // its tile position (rows at or above *lin_state are rotated by the reader) -- the decode attention then needs no slot table
+          const int h = jj / D, d = jj % D;
+          if (j < kd) k_lin[((size_t)h * (lin_rows >> 4) + (row >> 4)) * 2048 + (d >> 5) * 512 + (((d >> 3) & 3) * 16 + (row & 15)) * 8 + (d & 7)] = v;
+          else v_lin[((size_t)h * lin_rows + row) * D + d] = v;
+        }
       }
     }
   }
@@ -307,16 +316,30 @@ static inline bool smem_ok(int K) { return K > 0 && K % 8 == 0 && K <= 8192; }
     else KERNEL<ROWS, 4, 4> __VA_ARGS__;                                    \
   } while (0)
 
+extern "C" int svlm_dec_qkv_lin(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out,
+                                void* k_planes, void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd,
+                                int kd, int D, int n_slots, void* k_lin, void* v_lin, int lin_rows, void* stream);
 extern "C" int svlm_dec_qkv(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out,
                             void* k_planes, void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd,
                             int kd, int D, int n_slots, void* stream) {
+  return svlm_dec_qkv_lin(x, ln_w, eps, W, ldw, bias, q_out, k_planes, v_planes, slot_of, len_dev, len_host, K, qd, kd, D, n_slots, nullptr, nullptr,
+                          0, stream);
+}
+
+// k_lin / v_lin (optional, together): the layer's linear planes of lin_rows rows (svlm_decode_attn_lin); the new token's K row goes there
+// too, UN-rotated, at its logical row, and its V row as it is.
+extern "C" int svlm_dec_qkv_lin(const void* x, const void* ln_w, float eps, const void* W, int ldw, const void* bias, void* q_out,
+                                void* k_planes, void* v_planes, const int* slot_of, const int* len_dev, int len_host, int K, int qd,
+                                int kd, int D, int n_slots, void* k_lin, void* v_lin, int lin_rows, void* stream) {
+  SVLM_CHECK_ARG((k_lin == nullptr) == (v_lin == nullptr) && (k_lin == nullptr || (D == 128 && lin_rows > 0 && lin_rows % 16 == 0 && (len_dev != nullptr || len_host < lin_rows))),
+                 "svlm_dec_qkv_lin: k_lin / v_lin come together, head_dim 128, lin_rows=%d a multiple of 16 above the row", lin_rows);
   SVLM_CHECK_ARG(smem_ok(K) && ldw >= K && ldw % 8 == 0, "svlm_dec_qkv: bad K=%d ldw=%d", K, ldw);
   SVLM_CHECK_ARG(qd > 0 && kd > 0 && D > 0 && kd % D == 0 && n_slots > 0 && bias != nullptr, "svlm_dec_qkv: bad qd=%d kd=%d D=%d", qd, kd, D);
   const int N = qd + 2 * kd;
   // one row per wave: two rows per wave were measured on the 7B shape (4608 x 3584) and are slower (9.96 vs 8.8 us)
   DEC_DISPATCH(dec_qkv_kernel, 1, K, <<<(N + 3) / 4, 256, K * 2, (hipStream_t)stream>>>(
       (const bf16_t*)x, (const bf16_t*)ln_w, eps, (const bf16_t*)W, ldw, (const bf16_t*)bias, (bf16_t*)q_out, (bf16_t*)k_planes,
-      (bf16_t*)v_planes, slot_of, len_dev, len_host, N, K, qd, kd, D, n_slots));
+      (bf16_t*)v_planes, slot_of, len_dev, len_host, N, K, qd, kd, D, n_slots, (bf16_t*)k_lin, (bf16_t*)v_lin, lin_rows));
   return svlm_check_launch("svlm_dec_qkv");
 }
 

@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void rope_gather_kernel(const bf16_t* __restri
   constexpr int D = 128, CPR = 16;
   const long nk = (long)Hkv * L * CPR, nq = (long)T * Hq * CPR;
   const long total = 2 * nk + nq;
-  if (lin_len_dev != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *lin_len_dev = L;
+  if (lin_len_dev != nullptr && blockIdx.x == 0 && threadIdx.x == 0) { lin_len_dev[0] = L; lin_len_dev[1] = 1; }   // {rows rotated, appended rows follow}
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     if (i >= nk && i < 2 * nk) {                      // V: plain gather (new rows: taken from the projection output and APPENDED)
       const long t = i - nk;
@@ -764,7 +764,7 @@ extern "C" long long svlm_prefill_attn_ws_bytes(int T, int L, int Hq, int Hkv) {
 
 // LLM prefill: q (T, Hq*128) un-rotated rows, pool planes of one layer, out (T, Hq*128).
 // k_lin / v_lin / lin_len_dev (optional, together): the layer's linear planes of lin_rows rows (svlm_decode_attn_lin); the launch that
-// rotates and gathers the keys for this prefill also leaves them there and sets *lin_len_dev = L.
+// rotates and gathers the keys for this prefill also leaves them there and sets lin_len_dev[0..1] = {L, 1}.
 extern "C" int svlm_prefill_attn_ropeload_lin(const void* q, int q_stride, const void* k_new, const void* v_new, int kv_new_stride,
                                               void* k_planes, void* v_planes, const int* slot_of,
                                               const void* rope_cs, void* out, int o_stride, int T, int L, int Hq, int Hkv, int D,

@@ -546,6 +546,9 @@ class SvlmEngine:
                 o.gemm(hm, lw["down_w"], residual=x, out=x)
         if lin is not None:
             c.lin_written(L)
+            if self.decode_tail:          # svlm_dec_tail's QKV appends to the pool only: the attention takes the appended rows from there
+                c.lin_appends_off()
+                c.sync_device()
         if not head:
             return
         last = x[T - 1:T].contiguous()
@@ -577,7 +580,7 @@ class SvlmEngine:
                 o.dec_tail(self.d_attn, self.d_x, lw["o_w"], lw["ln2"], lw["gu_w"], lw["down_w"], tc.rms_eps, self.tail_ws, li, nl, nxt=nxt)
         for li, lw in enumerate(w.layers if not self.decode_tail else ()):
             o.dec_qkv(self.d_x, lw["ln1"], tc.rms_eps, lw["qkv_w"], lw["qkv_b"], self.d_qkv, c.pool, li, c.slot_of_dev, qd, kd,
-                      len_dev=kv_len)
+                      len_dev=kv_len, lin=lin)
             o.decode_attn(self.d_qkv[:qd], c.pool, li, c.slot_of_dev, self.rope_cs, self.d_attn, self.d_ws, tc.num_heads,
                           self._attn_len, self.decode_chunk, scale, length=1, len_dev=kv_len, lin=lin)
             o.gemv(self.d_attn, lw["o_w"], residual=self.d_x, out=self.d_x)

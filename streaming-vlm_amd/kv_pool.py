@@ -13,7 +13,9 @@ Beside the pool the cache holds its LINEAR PLANES ``lin[layer][kv][Hkv][lin_rows
 operand layout) and the values of rows ``[0, lin_valid)`` in logical order, as the prefill of the current chunk gathered them
 (``svlm_prefill_attn_ropeload_lin``).  The reference rotates every cached key in every forward (qwen2/language_forward.py:55-63);
 the positions of cached rows only change when the host edits the logical order, so the decode steps of a chunk stream that copy
-(``svlm_decode_attn_lin``) and take only the rows appended since from the pool.  Every edit of the logical order lowers ``lin_valid``.
+(``svlm_decode_attn_lin``); the rows appended since are written there too by the decode step's QKV launch (``svlm_dec_qkv_lin``, keys
+un-rotated: the attention rotates those few while it stages them), so a decode step reads no slot table at all.  The state the kernels
+see is ``lin_len_dev = {rows rotated, appended rows follow}``; every edit of the logical order lowers the first and clears the second.
 """
 from __future__ import annotations
 
@@ -81,9 +83,10 @@ class KVPool:
         # linear planes (module docstring): rows never read above lin_valid, so no initialisation
         self.lin_rows = -(-self.max_len // 16) * 16
         self.lin = torch.empty((n_layers, 2, n_kv_heads, self.lin_rows, head_dim), dtype=torch.bfloat16, device=device) if linear_planes else None
-        self.lin_len_dev = torch.zeros(1, dtype=torch.int32, device=device)
-        self.lin_valid = 0        # host mirror of *lin_len_dev
-        self._lin_dirty = False   # lin_valid lowered on the host since the device copy was written
+        self.lin_len_dev = torch.zeros(2, dtype=torch.int32, device=device)      # {rows rotated, appended rows follow}
+        self.lin_valid = 0        # host mirror of lin_len_dev[0]
+        self.lin_fresh = False    # host mirror of lin_len_dev[1]: rows [lin_valid, length) are in the planes too (keys un-rotated)
+        self._lin_dirty = False   # lowered / cleared on the host since the device copy was written
         self._half = {}           # layer -> (which, rows): one plane assigned, waiting for its partner
         self._upd_rows = 0        # rows of an update() pass that has not reached the last layer yet
 
@@ -95,12 +98,17 @@ class KVPool:
     def lin_written(self, L: int):
         """The prefill's gather launches have left rows [0, L) of every layer in the linear planes (and L in *lin_len_dev)."""
         if self.lin is not None:
-            self.lin_valid, self._lin_dirty = int(L), False
+            self.lin_valid, self.lin_fresh, self._lin_dirty = int(L), True, False
 
     def _lin_touch(self, first_row: int):
-        """Logical rows >= first_row no longer are what the linear planes hold."""
-        if first_row < self.lin_valid:
-            self.lin_valid, self._lin_dirty = max(int(first_row), 0), True
+        """Logical rows >= first_row no longer are what the linear planes hold (nor do rows appended from now on go there in order)."""
+        if self.lin is not None and (first_row < self.lin_valid or self.lin_fresh):
+            self.lin_valid, self.lin_fresh, self._lin_dirty = max(min(int(first_row), self.lin_valid), 0), False, True
+
+    def lin_appends_off(self):
+        """The decode steps that follow do not write their rows into the linear planes (svlm_dec_tail's QKV): rows above lin_valid
+        are read from the pool."""
+        self._lin_touch(self.lin_valid)
 
     # ------------------------------------------------------------------ allocation
     def _take_slot(self) -> int:
@@ -194,7 +202,7 @@ class KVPool:
             self.slot_of_dev[lo:hi].copy_(torch.from_numpy(self.slot_of[lo:hi].copy()))
         self._dirty_from = self.max_len
         if self._lin_dirty:
-            self.lin_len_dev.fill_(self.lin_valid)
+            self.lin_len_dev.copy_(torch.tensor([self.lin_valid, int(self.lin_fresh)], dtype=torch.int32))
             self._lin_dirty = False
 
     def fragmentation(self) -> float:

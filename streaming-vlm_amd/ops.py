@@ -428,11 +428,12 @@ class HipOps:
 
     @staticmethod
     def _lin_args(lin, layer, Hkv, D, need_rows, what):
-        """lin = (planes (n_layers, 2, Hkv, lin_rows, D) bf16, lin_len_dev int32[1]) or None -> (k_lin, v_lin, lin_rows, lin_len_dev)"""
+        """lin = (planes (n_layers, 2, Hkv, lin_rows, D) bf16, lin_state int32[2]) or None -> (k_lin, v_lin, lin_rows, lin_state)"""
         if lin is None:
             return None, None, 0, None
         planes, lin_len = lin
-        _req(planes, BF16, what + ".lin", 5); _req(lin_len, torch.int32, what + ".lin_len", 1)
+        _req(planes, BF16, what + ".lin", 5); _req(lin_len, torch.int32, what + ".lin_state", 1)
+        assert lin_len.numel() == 2, "lin_state = {rows rotated, appended rows follow}"
         assert planes.shape[1] == 2 and planes.shape[2] == Hkv and planes.shape[4] == D and planes.is_contiguous(), tuple(planes.shape)
         assert planes.shape[3] % 16 == 0 and planes.shape[3] >= need_rows, (planes.shape[3], need_rows)
         return planes[layer, 0], planes[layer, 1], planes.shape[3], lin_len
@@ -528,7 +529,9 @@ class HipOps:
                                            _stream()), "svlm_penalty_sample")
 
     # ------------------------------------------------------------------ fused decode step
-    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
+    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None, lin=None):
+        """lin: the cache's linear planes (KVPool.lin_args()): the new row goes there too (key un-rotated), so that the decode attention
+        finds the rows appended since the prefill without the slot table."""
         _req(x, BF16, "dec_qkv.x", 1); _req(ln_w, BF16, "dec_qkv.ln_w", 1); _req(W, BF16, "dec_qkv.W", 2)
         _req(bias, BF16, "dec_qkv.bias", 1); _req(q_out, BF16, "dec_qkv.q_out", 1); _req(slot_of, torch.int32, "dec_qkv.slot_of", 1)
         _, _, Hkv, n_slots, D = pool.shape
@@ -537,8 +540,10 @@ class HipOps:
         if len_dev is None:
             assert 0 <= length < slot_of.numel()
         kp, vp = self._planes(pool, layer)
-        check(self.lib.svlm_dec_qkv(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(q_out), _ptr(kp), _ptr(vp),
-                                    _ptr(slot_of), _ptr(len_dev), int(length), K, qd, kd, D, n_slots, _stream()), "svlm_dec_qkv")
+        kl, vl, lin_rows, _ = self._lin_args(lin, layer, Hkv, D, length + 1 if len_dev is None else 1, "dec_qkv")
+        check(self.lib.svlm_dec_qkv_lin(_ptr(x), _ptr(ln_w), float(eps), _ptr(W), W.stride(0), _ptr(bias), _ptr(q_out), _ptr(kp), _ptr(vp),
+                                        _ptr(slot_of), _ptr(len_dev), int(length), K, qd, kd, D, n_slots, _ptr(kl), _ptr(vl), lin_rows,
+                                        _stream()), "svlm_dec_qkv_lin")
 
     def dec_gate_up(self, x, ln_w, eps, W, h):
         _req(x, BF16, "dec_gate_up.x", 1); _req(ln_w, BF16, "dec_gate_up.ln_w", 1); _req(W, BF16, "dec_gate_up.W", 2); _req(h, BF16, "dec_gate_up.h", 1)

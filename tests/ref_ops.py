@@ -211,6 +211,10 @@ class RefOps:
                 Kr = self._rot(pool[layer, 0][:, sl], rope_cs, torch.arange(n))
                 assert torch.equal(self.lin_k_rows(planes[layer, 0], n), Kr), f"stale rotated keys in the linear planes (layer {layer}, {n} rows)"
                 assert torch.equal(planes[layer, 1][:, :n], pool[layer, 1][:, sl]), f"stale values in the linear planes (layer {layer}, {n} rows)"
+            if int(lin_len[1]) and L > n:       # the appended rows the kernel would take from the planes (keys un-rotated)
+                sl = slot_of[n:L].long()
+                assert torch.equal(self.lin_k_rows(planes[layer, 0], L)[:, n:], pool[layer, 0][:, sl]), f"appended keys missing from the linear planes (layer {layer}, rows {n}..{L})"
+                assert torch.equal(planes[layer, 1][:, n:L], pool[layer, 1][:, sl]), f"appended values missing from the linear planes (layer {layer}, rows {n}..{L})"
         o = self._attend(q.view(Hq, 1, D), pool, layer, slot_of, rope_cs, 1, L, Hq, scale)
         out.copy_(o.reshape(out.shape))
         return out
@@ -224,7 +228,7 @@ class RefOps:
             sl = slot_of[:L].long()
             planes[layer, 0] = self.lin_k_tiles(self._rot(pool[layer, 0][:, sl], rope_cs, torch.arange(L)), planes.shape[3])
             planes[layer, 1][:, :L] = pool[layer, 1][:, sl]
-            lin_len[0] = L
+            lin_len[0], lin_len[1] = L, 1
         o = self._attend(q[:T].reshape(T, Hq, D).transpose(0, 1), pool, layer, slot_of, rope_cs, T, L, Hq, scale)
         out[:T] = o.transpose(0, 1).reshape(T, Hq * D)
         return out
@@ -263,10 +267,18 @@ class RefOps:
     def sampling_ws(self, V, device):
         return torch.zeros(4, dtype=torch.float32)
 
-    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None):
+    def dec_qkv(self, x, ln_w, eps, W, bias, q_out, pool, layer, slot_of, qd, kd, length=0, len_dev=None, lin=None):
         y = F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W, bias)[0]
         q_out[:qd] = y[:qd]
         self.kv_append(y[qd:qd + kd].reshape(1, -1), y[qd + kd:].reshape(1, -1), pool, layer, slot_of, length, 1, len_dev=len_dev)
+        if lin is not None:          # the appended row also goes to the linear planes: V as it is, K un-rotated in its tile position
+            planes = lin[0]
+            row = int(len_dev[0]) if len_dev is not None else length
+            Hkv, D = planes.shape[2], planes.shape[4]
+            k = y[qd:qd + kd].reshape(Hkv, D)
+            t, r = row // 16, row % 16
+            planes[layer, 0].view(Hkv, -1, 4, 4, 16, 8)[:, t, :, :, r, :] = k.view(Hkv, 4, 4, 8)
+            planes[layer, 1][:, row] = y[qd + kd:].reshape(Hkv, D)
 
     def dec_gate_up(self, x, ln_w, eps, W, h):
         y = F.linear(om.rms_norm(x.reshape(1, -1), ln_w, eps), W)

@@ -235,15 +235,18 @@ def test_linear_planes_validity_follows_every_edit_of_the_logical_order():
     pool = _pool(max_len=256, pages=16)
     pool.slot_of_dev = torch.from_numpy(pool.slot_of)
     assert pool.lin is not None and pool.lin.shape == (2, 2, 2, 256, 128) and pool.lin_args()[1] is pool.lin_len_dev
+    dev_state = lambda: pool.lin_len_dev.tolist()                # {rows rotated, appended rows follow}
     _fill(pool, 200, 0)
-    pool.lin_written(200); pool.lin_len_dev.fill_(200)           # what the gather launches of a prefill do
+    pool.lin_written(200); pool.lin_len_dev.copy_(torch.tensor([200, 1], dtype=torch.int32))   # what the gather launches of a prefill do
     pool.reserve(20); pool.commit(210); pool.release_reserved()  # decode steps: appended rows, unused tail given back
     pool.sync_device()
-    assert pool.lin_valid == 200 and int(pool.lin_len_dev[0]) == 200
+    assert pool.lin_valid == 200 and pool.lin_fresh and dev_state() == [200, 1]
     pool.move(150, 160, 99)
-    assert pool.lin_valid == 100 and int(pool.lin_len_dev[0]) == 200          # host first ...
+    assert pool.lin_valid == 100 and not pool.lin_fresh and dev_state() == [200, 1]      # host first ...
     pool.sync_device()
-    assert int(pool.lin_len_dev[0]) == 100                                     # ... the device at the next sync
+    assert dev_state() == [100, 0]                                                        # ... the device at the next sync
+    pool.lin_written(100); pool.lin_appends_off(); pool.sync_device()                     # a decode step that does not maintain the planes
+    assert pool.lin_valid == 100 and dev_state() == [100, 0]
     pool.prune(120, 130)
     assert pool.lin_valid == 100
     pool.prune(40, 50)
@@ -251,19 +254,19 @@ def test_linear_planes_validity_follows_every_edit_of_the_logical_order():
     pool.defragment()
     assert pool.lin_valid == 40
     pool.truncate(30); pool.sync_device()
-    assert pool.lin_valid == 30 and int(pool.lin_len_dev[0]) == 30
+    assert pool.lin_valid == 30 and dev_state() == [30, 0]
     pool.lin_written(30)
     g = torch.Generator().manual_seed(1)
     k, v = (torch.randn(1, 2, 7, 128, generator=g).to(torch.bfloat16) for _ in range(2))
     for layer in range(2):
         pool.update(k, v, layer)                                 # rows that exist in the pool only
-    assert pool.lin_valid == 30 and pool.get_seq_length() == 37
+    assert pool.lin_valid == 30 and not pool.lin_fresh and pool.get_seq_length() == 37
     pool.lin_written(37)
     for i, (kk, vv) in enumerate(list(pool)):
         pool.key_cache[i] = kk[:, :, :20]
         pool.value_cache[i] = vv[:, :, :20]
     pool.sync_device()
-    assert pool.lin_valid == 0 and int(pool.lin_len_dev[0]) == 0
+    assert pool.lin_valid == 0 and dev_state() == [0, 0]
     bare = S.KVPool(2, 2, 128, 64, "cpu", RefOps(), linear_planes=False)
     assert bare.lin is None and bare.lin_args() is None
     bare.lin_written(10)

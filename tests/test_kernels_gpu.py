@@ -335,8 +335,9 @@ def test_decode_attn(ops, ref, Hq, Hkv, L, chunk):
                                               (12, 2, 9000, 256, 500), (28, 4, 4400, 128, 4400), (12, 2, 2352, 192, 100), (6, 1, 8191, 512, 31),
                                               (4, 2, 300, 128, 300)])
 def test_decode_attn_from_the_linear_planes_the_prefill_leaves(ops, ref, Hq, Hkv, L, chunk, T):
-    """svlm_prefill_attn_ropeload_lin leaves rotated keys (tile layout of include/svlm.h) + values of rows [0, L) and *lin_len = L;
-    svlm_decode_attn_lin must give the SAME BITS as the pool path for every later length and for every validity bound."""
+    """svlm_prefill_attn_ropeload_lin leaves rotated keys (tile layout of include/svlm.h) + values of rows [0, L) and lin_state = {L, 1};
+    svlm_dec_qkv_lin adds every appended row (key un-rotated); svlm_decode_attn_lin must give the SAME BITS as the pool path for every
+    later length, every validity bound, with and without the appended rows in the planes."""
     from ref_ops import RefOps
     new = 24                                       # rows appended after the prefill (decode steps)
     cap = ((L + new + 63) // 64) * 64 + 64
@@ -344,38 +345,59 @@ def test_decode_attn_from_the_linear_planes_the_prefill_leaves(ops, ref, Hq, Hkv
     scale = 1 / math.sqrt(128)
     pg, sg, rg = pool.cuda(), slot_of.cuda(), rope.cuda()
     lin_rows = -(-cap // 16) * 16
-    planes = torch.full((1, 2, Hkv, lin_rows, 128), float("nan"), dtype=BF16, device="cuda")      # never read above *lin_len
-    lin_len = torch.zeros(1, dtype=torch.int32, device="cuda")
+    planes = torch.full((1, 2, Hkv, lin_rows, 128), float("nan"), dtype=BF16, device="cuda")      # never read above the rows written
+    lin_state = torch.zeros(2, dtype=torch.int32, device="cuda")
     qp = rnd((T, Hq * 128), 6).cuda()
     out_p, out_p2 = torch.empty((T, Hq * 128), dtype=BF16, device="cuda"), torch.empty((T, Hq * 128), dtype=BF16, device="cuda")
     ops.prefill_attn(qp, pg, 0, sg, rg, out_p, T, L, Hq, scale)
-    ops.prefill_attn(qp, pg, 0, sg, rg, out_p2, T, L, Hq, scale, lin=(planes, lin_len))
-    assert torch.equal(out_p, out_p2) and int(lin_len[0]) == L
+    ops.prefill_attn(qp, pg, 0, sg, rg, out_p2, T, L, Hq, scale, lin=(planes, lin_state))
+    assert torch.equal(out_p, out_p2) and lin_state.tolist() == [L, 1]
     Kr = ref._rot(pool[0, 0][:, slot_of[:L].long()], rope, torch.arange(L))
     assert torch.equal(RefOps.lin_k_rows(planes[0, 0].cpu(), L), Kr), "rotated keys in the linear planes"
     assert torch.equal(planes[0, 1][:, :L].cpu(), pool[0, 1][:, slot_of[:L].long()]), "values in the linear planes"
+    # ---- decode steps append rows L .. L + new - 1 through the QKV launch: pool slot AND linear planes
+    qd, kd, Kx = Hq * 128, Hkv * 128, 256
+    W, bias, lnw = rnd((qd + 2 * kd, Kx), 7, 0.08).cuda(), rnd((qd + 2 * kd,), 8).cuda(), (rnd((Kx,), 9) + 1).cuda()
+    q_out = torch.empty(qd, dtype=BF16, device="cuda")
+    len_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for r in range(L, L + new):
+        x = rnd((Kx,), 100 + r).cuda()
+        if r % 2:
+            ops.dec_qkv(x, lnw, 1e-6, W, bias, q_out, pg, 0, sg, qd, kd, length=r, lin=(planes, lin_state))
+        else:
+            len_dev.fill_(r)
+            ops.dec_qkv(x, lnw, 1e-6, W, bias, q_out, pg, 0, sg, qd, kd, len_dev=len_dev, lin=(planes, lin_state))
+    rows_new = slot_of[L:L + new].long()
+    pool2 = pg.cpu()
+    assert torch.equal(RefOps.lin_k_rows(planes[0, 0].cpu(), L + new)[:, L:], pool2[0, 0][:, rows_new]), "appended keys (un-rotated) in the linear planes"
+    assert torch.equal(planes[0, 1][:, L:L + new].cpu(), pool2[0, 1][:, rows_new]), "appended values in the linear planes"
+    assert torch.equal(RefOps.lin_k_rows(planes[0, 0].cpu(), L), Kr), "the appends left the rotated rows alone"
     ws = ops.decode_attn_ws(Hq, cap, chunk, "cuda")
     q = rnd((Hq * 128,), 3).cuda()
-    for Ld in (L, L + 1, L + new):                 # the prefill's own length, the first decode step, the last one
+    for Ld in (L, L + 1, L + 7, L + new):          # the prefill's own length, the first decode step, one in the middle, the last one
         want = torch.empty(Hq * 128, dtype=BF16, device="cuda")
         ops.decode_attn(q, pg, 0, sg, rg, want, ws, Hq, cap, chunk, scale, length=Ld)
         for valid in sorted({L, max(L - 1, 0), L // 2, (L // 16) * 16, min(L, 15), 0}):
-            lin_len.fill_(valid)
-            got = torch.full_like(want, float("nan"))
-            ops.decode_attn(q, pg, 0, sg, rg, got, ws, Hq, cap, chunk, scale, length=Ld, lin=(planes, lin_len))
-            assert torch.equal(got, want), f"L={Ld} lin_len={valid}: linear planes and pool path differ"
-            len_dev = torch.tensor([Ld - 1], dtype=torch.int32, device="cuda")
-            got2 = torch.full_like(want, float("nan"))
-            ops.decode_attn(q, pg, 0, sg, rg, got2, ws, Hq, cap, chunk, scale, length=1, len_dev=len_dev, lin=(planes, lin_len))
-            assert torch.equal(got2, want), f"L={Ld} lin_len={valid} (device length)"
+            for fresh in (1, 0):
+                if fresh and valid != L:
+                    continue                    # appended rows follow a bound the prefill set; a lowered bound always clears the flag
+                lin_state.copy_(torch.tensor([valid, fresh], dtype=torch.int32))
+                got = torch.full_like(want, float("nan"))
+                ops.decode_attn(q, pg, 0, sg, rg, got, ws, Hq, cap, chunk, scale, length=Ld, lin=(planes, lin_state))
+                assert torch.equal(got, want), f"L={Ld} lin_state=({valid}, {fresh}): linear planes and pool path differ"
+                len_dev.fill_(Ld - 1)
+                got2 = torch.full_like(want, float("nan"))
+                ops.decode_attn(q, pg, 0, sg, rg, got2, ws, Hq, cap, chunk, scale, length=1, len_dev=len_dev, lin=(planes, lin_state))
+                assert torch.equal(got2, want), f"L={Ld} lin_state=({valid}, {fresh}) (device length)"
     # a bound ABOVE the cache length (a host that truncated without lowering it) is clamped, not trusted
-    lin_len.fill_(L)
     Ls = max(L - 20, 1)
     want = torch.empty(Hq * 128, dtype=BF16, device="cuda")
     ops.decode_attn(q, pg, 0, sg, rg, want, ws, Hq, cap, chunk, scale, length=Ls)
-    got = torch.empty_like(want)
-    ops.decode_attn(q, pg, 0, sg, rg, got, ws, Hq, cap, chunk, scale, length=Ls, lin=(planes, lin_len))
-    assert torch.equal(got, want)
+    for fresh in (0, 1):
+        lin_state.copy_(torch.tensor([L, fresh], dtype=torch.int32))
+        got = torch.empty_like(want)
+        ops.decode_attn(q, pg, 0, sg, rg, got, ws, Hq, cap, chunk, scale, length=Ls, lin=(planes, lin_state))
+        assert torch.equal(got, want)
 
 
 # (2,1,700,700) and (4,2,300,1000) run 5 / 7 key splits whose last ones start beyond some queries' causal limit (rows that

@@ -25,7 +25,7 @@ for Hq, Hkv, L in cases:
     q = torch.randn(Hq * D, device="cuda").to(bf)
     out = torch.empty(Hq * D, dtype=bf, device="cuda")
     lin_rows = -(-cap // 16) * 16
-    lins = [((torch.randn((1, 2, Hkv, lin_rows, D), device="cuda") * 0.5).to(bf), torch.tensor([L - 20], dtype=torch.int32, device="cuda"))
+    lins = [((torch.randn((1, 2, Hkv, lin_rows, D), device="cuda") * 0.5).to(bf), torch.tensor([L - 20, 1], dtype=torch.int32, device="cuda"))
             for _ in range(NP)] if LIN else [None] * NP
     nb = 2 * L * Hkv * D * 2 + L * 3 * 4
     line = []

@@ -40,7 +40,7 @@ elif which == "decode_attn":
     ch = int(os.environ.get("MB_CHUNK", 48))          # keys per workgroup: the engine's choice for bounded windows
     ws = o.decode_attn_ws(Hq, 2560, ch, dev)
     # MB_LIN=0: without the cache's linear planes (every row rotated from the pool); default: planes valid up to the rows decoded since the prefill
-    lin = (r(1, 2, Hkv, 2560, 128), torch.tensor([L - 10], dtype=torch.int32, device=dev)) if os.environ.get("MB_LIN", "1") != "0" else None
+    lin = (r(1, 2, Hkv, 2560, 128), torch.tensor([L - 10, 1], dtype=torch.int32, device=dev)) if os.environ.get("MB_LIN", "1") != "0" else None
     fn = lambda: o.decode_attn(q, pool, 0, slot, rope, out, ws, Hq, 2560, ch, 128 ** -0.5, length=L, lin=lin)
 elif which == "decode_attn_long":
     # long-cache streaming kernel: 8 cold pools at MB_L keys (default 32768) with MB_HEADS = "Hq,Hkv" (default the 7B's 28,4)
@@ -52,7 +52,7 @@ elif which == "decode_attn_long":
     ch = SvlmEngine.pick_decode_chunk(cap, Hkv, use_lin)
     pools = [r(1, 2, Hkv, cap, 128) for _ in range(8)]
     lin_rows = -(-cap // 16) * 16
-    lins = [(r(1, 2, Hkv, lin_rows, 128), torch.tensor([L - 16], dtype=torch.int32, device=dev)) if use_lin else None for _ in range(8)]
+    lins = [(r(1, 2, Hkv, lin_rows, 128), torch.tensor([L - 16, 1], dtype=torch.int32, device=dev)) if use_lin else None for _ in range(8)]
     slot = torch.arange(cap, dtype=torch.int32, device=dev)
     rope = r(cap, 128)
     q, out = r(Hq * 128), torch.empty(Hq * 128, dtype=bf, device=dev)
