@@ -234,7 +234,8 @@ def main():
                                f"window={args.window}, {args.new_tokens} {'greedy' if args.sampling == 'greedy' else 'sampled (' + args.sampling + ')'} tokens/chunk, one stream per GPU",
                    "frames_per_chunk": frames_per_chunk, "new_tokens_per_chunk": args.new_tokens, "kv_len_steady": kv_steady[0],
                    "kv_fill_chunks": fill, "vit_passes_in_timed_region": args.steps, "parallelism": f"streams{world}",
-                   "decode_step": "persistent layer tail (svlm_dec_tail), 3 launches per layer" if args.decode_tail else "per-op launches, 6 per layer"},
+                   "decode_step": "persistent layer tail (svlm_dec_tail), 3 launches per layer" if args.decode_tail else "per-op launches, 6 per layer",
+                   "kv_layout": "slot-mapped pool of un-rotated keys + linear planes of the chunk's rotated keys" if model._svlm_engine.linear_planes else "slot-mapped pool of un-rotated keys, rotated on load"},
         "per_gpu_frames_per_sec": [round(v, 3) for v in per_gpu_fps],
         "per_gpu_min": round(min(per_gpu_fps), 3), "per_gpu_max": round(max(per_gpu_fps), 3),
         "per_gpu_stdev": round((sum((v - sum(per_gpu_fps) / len(per_gpu_fps)) ** 2 for v in per_gpu_fps) / len(per_gpu_fps)) ** 0.5, 4),
