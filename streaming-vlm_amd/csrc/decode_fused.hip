@@ -274,8 +274,35 @@ __global__ __launch_bounds__(1024) void argmax_finish_kernel(const float* __rest
                                                              int n_parts, unsigned char* seen, int* tok_buf, int* state, int advance_kv) {
   float best = -INFINITY;
   int bi = 0x7fffffff;
+  // the candidates are the output of the launch in front: every load here is a round trip to another CU's stores (~2 us each behind a
+  // kernel boundary), so ALL of them are requested before the first compare -- 16-B loads, six per thread (24k candidates), the rest
+  // (a vocabulary beyond 196k, an unaligned tail) in the plain loop
+  constexpr int VL = 6;
+  const int n4 = ((reinterpret_cast<uintptr_t>(part_val) | reinterpret_cast<uintptr_t>(part_idx)) & 15) == 0 ? n_parts >> 2 : 0;
+  f32x4_t vv[VL];
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  i32x4_t vi[VL];
+  if (n4 > 0) {                     // (kernel-uniform)
+#pragma unroll
+    for (int u = 0; u < VL; ++u) {
+      const int j = min((int)threadIdx.x + u * 1024, n4 - 1);
+      vv[u] = reinterpret_cast<const f32x4_t*>(part_val)[j];
+      vi[u] = reinterpret_cast<const i32x4_t*>(part_idx)[j];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < VL; ++u) {
+    if ((int)threadIdx.x + u * 1024 < n4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = vv[u][e];
+        const int n = vi[u][e];
+        if (v > best || (v == best && n < bi)) { best = v; bi = n; }
+      }
+    }
+  }
 #pragma unroll 4
-  for (int i = threadIdx.x; i < n_parts; i += 1024) {
+  for (int i = min(n4, VL * 1024) * 4 + threadIdx.x; i < n_parts; i += 1024) {
     const float v = part_val[i];
     const int n = part_idx[i];
     if (v > best || (v == best && n < bi)) { best = v; bi = n; }
