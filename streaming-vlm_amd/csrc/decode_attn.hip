@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
       vraw[it] = *reinterpret_cast<const u32x4_t*>(v_lin + ((size_t)kvh * lin_rows + lt * 16 + srow) * DA_D + c * 8);
     }
   }
+  // (the planes' state is read NEXT TO the length, not behind the branch on it: one scalar round trip, not two)
+  const int lin_r = (k_lin != nullptr && lin_len_dev != nullptr) ? lin_len_dev[0] : 0;
+  const int lin_f = (k_lin != nullptr && lin_len_dev != nullptr) ? lin_len_dev[1] : 0;
   const int L = (len_dev ? *len_dev : 0) + len_add;
   if (start >= L) return;
   DA_STAMP(wg_id, 1);
@@ -126,12 +129,8 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   // rows requested above as they are (wg_lin); the range that holds appended rows keeps them and rotates those (wg_fresh: their cos /
   // sin rows are requested only now, behind the length, but they are a few rows of a table every layer reads); without the fresh rows
   // (a host edit of the logical order since the prefill, a decode step that does not maintain the planes) it takes the pool path
-  int lin_rot = 0;
-  bool lin_fresh = false;
-  if (k_lin != nullptr && lin_len_dev != nullptr) {
-    lin_rot = min(lin_len_dev[0], L);
-    lin_fresh = lin_len_dev[1] != 0;
-  }
+  const int lin_rot = min(lin_r, L);
+  const bool lin_fresh = lin_f != 0;
   const bool wg_lin = start + chunk <= lin_rot;             // workgroup-uniform; implies n_rows == chunk
   const bool wg_fresh = !wg_lin && lin_fresh;               // workgroup-uniform
   if (wg_fresh) {
@@ -550,6 +549,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     }
     *reinterpret_cast<u32x4_t*>(Qs + srow * DA_KLD + c * 8) = outq;
   }
+  const int lin_r = WLIN ? lin_len_dev[0] : 0, lin_f = WLIN ? lin_len_dev[1] : 0;      // (next to the length: one scalar round trip)
   const int L = (len_dev ? *len_dev : 0) + len_add;
   if (start >= L) {                                         // workgroup-uniform
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the requested tile must have landed before the wave's registers are released)
@@ -560,8 +560,8 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   // WLIN: rows [0, lin_len) of the cache also exist ROTATED, in logical order, in the linear planes the prefill left behind (header of
   // svlm_decode_attn_lin): tiles that lie there are streamed from them (no slot table, no cos/sin rows, no rotation).  Without
   // linear planes (!WLIN) the kernel is the pipelined pool path alone.
-  const int lin_len = WLIN ? min(lin_len_dev[0], L) : 0;
-  const bool lin_fresh = WLIN ? lin_len_dev[1] != 0 : false;        // rows above lin_len are in the planes too, un-rotated (svlm_dec_qkv_lin)
+  const int lin_len = min(lin_r, L);
+  const bool lin_fresh = lin_f != 0;                        // rows above lin_len are in the planes too, un-rotated (svlm_dec_qkv_lin)
   lds_barrier();                                            // Qs visible (LDS only: the tile requested above stays in flight)
   bf16x8_t qf[4];                                           // this lane's B fragments of the query block: constant over the loop
 #pragma unroll
