@@ -44,6 +44,7 @@ __device__ __forceinline__ void rope8(const float (&x)[8], const float (&xp)[8],
 typedef short v4s_da_t __attribute__((ext_vector_type(4)));
 #define DA_KLD 136   // K / Q LDS row stride (bf16): 272 B, conflict-free ds_read_b128 fragments
 #define DA_VLD 144   // V LDS row stride (bf16): 288 B, conflict-free ds_read_b64_tr_b16
+#define DA_OLD 132   // merge-buffer row stride (fp32): 528 B -- at 512 B the 16-B accumulator stores of the G head rows all hit the same banks (4.3 conflict cycles per LDS instruction, profiles/pmc_waits.json)
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u(unsigned v) { return __builtin_amdgcn_update_dpp(0u, v, CTRL, 0xF, 0xF, true); }
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   bf16_t* Ks = reinterpret_cast<bf16_t*>(lds);
   bf16_t* Vs = Ks + 64 * DA_KLD;
   bf16_t* Qs = Vs + 64 * DA_VLD;
-  float* Om = reinterpret_cast<float*>(lds);                     // [4][16][128] fp32, reuses Ks/Vs after the tiles are consumed
+  float* Om = reinterpret_cast<float*>(lds);                     // [4][16][DA_OLD] fp32 (33 KB of the 35 KB of Ks + Vs), reuses them after the tiles are consumed
   float* Mm = reinterpret_cast<float*>(lds + 64 * DA_KLD * 2 + 64 * DA_VLD * 2 + 16 * DA_KLD * 2);   // [4][16]
   float* Lm = Mm + 64;
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   __syncthreads();          // every wave is done with Ks / Vs: the region becomes the merge buffer
   if (fr < G) {
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_D) + dt * 16 + fq * 4) = oacc[dt];
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_OLD) + dt * 16 + fq * 4) = oacc[dt];
     if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
   }
   __syncthreads();
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
     for (int w = 0; w < 4; ++w) {
       const float e = __expf(Mm[w * 16 + g] - mn);
       l += Lm[w * 16 + g] * e;
-      a += Om[(w * 16 + g) * DA_D + d] * e;
+      a += Om[(w * 16 + g) * DA_OLD + d] * e;
     }
     const int hq = kvh * G + g;
     ws_acc[(part + hq) * DA_D + d] = a;
@@ -496,11 +497,11 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     float* __restrict__ ws_m, float* __restrict__ ws_l, float* __restrict__ ws_acc, int Hq, int Hkv, int n_slots,
     int chunk, float scale, int max_len, const bf16_t* __restrict__ k_lin, const bf16_t* __restrict__ v_lin, int lin_rows,
     const int* __restrict__ lin_len_dev) {
-  // LDS: [4][16][128] fp32 merge buffer (32 KB), whose first 18 KB double as the four waves' V slabs during the loop; Q block; m / l
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 16 * DA_D * 4 + 16 * DA_KLD * 2 + 512];
+  // LDS: [4][16][DA_OLD] fp32 merge buffer (33 KB), whose first 18 KB double as the four waves' V slabs during the loop; Q block; m / l
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 16 * DA_OLD * 4 + 16 * DA_KLD * 2 + 512];
   float* Om = reinterpret_cast<float*>(lds);
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(lds + 4 * 16 * DA_D * 4);
-  float* Mm = reinterpret_cast<float*>(lds + 4 * 16 * DA_D * 4 + 16 * DA_KLD * 2);
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(lds + 4 * 16 * DA_OLD * 4);
+  float* Mm = reinterpret_cast<float*>(lds + 4 * 16 * DA_OLD * 4 + 16 * DA_KLD * 2);
   float* Lm = Mm + 64;
 
   // the LAST key range is dispatched FIRST: it is the one that holds the rows appended since the prefill (pool path below, slower per tile)
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   __syncthreads();                                          // every wave is done with its V slab: the region becomes the merge buffer
   if (fr < G) {
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_D) + dt * 16 + fq * 4) = oacc[dt];
+    for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4_t*>(Om + ((wave * 16 + fr) * DA_OLD) + dt * 16 + fq * 4) = oacc[dt];
     if (fq == 0) { Mm[wave * 16 + fr] = m_w; Lm[wave * 16 + fr] = l_w; }
   }
   __syncthreads();
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
     for (int w = 0; w < 4; ++w) {
       const float e = __expf(Mm[w * 16 + g] - mn);
       l += Lm[w * 16 + g] * e;
-      a += Om[(w * 16 + g) * DA_D + d] * e;
+      a += Om[(w * 16 + g) * DA_OLD + d] * e;
     }
     const int hq = kvh * G + g;
     ws_acc[(part + hq) * DA_D + d] = a;
