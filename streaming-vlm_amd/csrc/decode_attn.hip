@@ -251,20 +251,23 @@ __global__ __launch_bounds__(256) void decode_attn_split_kernel(
   __syncthreads();
   DA_STAMP(wg_id, 5);
   const size_t part = (size_t)blockIdx.x * Hq;
-  for (int idx = tid; idx < G * DA_D; idx += 256) {
-    const int g = idx / DA_D, d = idx % DA_D;
+  if (tid < G * 32) {               // one pass: thread (head g, four columns) -- the four waves' weights once per thread, 16-B LDS reads and stores
+    const int g = tid >> 5, d = (tid & 31) * 4;
     float mn = Mm[g];
 #pragma unroll
     for (int w = 1; w < 4; ++w) mn = fmaxf(mn, Mm[w * 16 + g]);
-    float l = 0.f, a = 0.f;
+    float l = 0.f;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float e = __expf(Mm[w * 16 + g] - mn);
       l += Lm[w * 16 + g] * e;
-      a += Om[(w * 16 + g) * DA_OLD + d] * e;
+      const f32x4_t o = *reinterpret_cast<const f32x4_t*>(Om + (w * 16 + g) * DA_OLD + d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] += o[i] * e;
     }
     const int hq = kvh * G + g;
-    ws_acc[(part + hq) * DA_D + d] = a;
+    *reinterpret_cast<f32x4_t*>(ws_acc + (part + hq) * DA_D + d) = a;
     if (d == 0) { ws_m[part + hq] = mn; ws_l[part + hq] = l; }
   }
   DA_STAMP(wg_id, 6);
@@ -738,20 +741,23 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
   }
   __syncthreads();
   const size_t part = (size_t)sp * Hq;
-  for (int idx = tid; idx < G * DA_D; idx += 256) {
-    const int g = idx / DA_D, d = idx % DA_D;
+  if (tid < G * 32) {               // thread (head g, four columns), as in the bounded-window kernel
+    const int g = tid >> 5, d = (tid & 31) * 4;
     float mn = Mm[g];
 #pragma unroll
     for (int w = 1; w < 4; ++w) mn = fmaxf(mn, Mm[w * 16 + g]);
-    float l = 0.f, a = 0.f;
+    float l = 0.f;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float e = __expf(Mm[w * 16 + g] - mn);
       l += Lm[w * 16 + g] * e;
-      a += Om[(w * 16 + g) * DA_OLD + d] * e;
+      const f32x4_t o = *reinterpret_cast<const f32x4_t*>(Om + (w * 16 + g) * DA_OLD + d);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] += o[i] * e;
     }
     const int hq = kvh * G + g;
-    ws_acc[(part + hq) * DA_D + d] = a;
+    *reinterpret_cast<f32x4_t*>(ws_acc + (part + hq) * DA_D + d) = a;
     if (d == 0) { ws_m[part + hq] = mn; ws_l[part + hq] = l; }
   }
 }
