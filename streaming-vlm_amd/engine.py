@@ -299,6 +299,12 @@ class SvlmEngine:
             self._tok_ev = torch.cuda.Event()
             self._poll_host = [torch.zeros(self.max_new + 1, dtype=torch.int32).pin_memory() for _ in range(2)]      # EOS looks, one behind
             self._poll_ev = [torch.cuda.Event(), torch.cuda.Event()]
+        # host -> device copies of a chunk's start (ids, grids, positions, gather indices, state) go through this page-locked arena and are
+        # truly asynchronous: a copy from pageable memory makes the host wait for everything enqueued in front of it -- the look-ahead
+        # ViT's tail, which exists to run UNDERNEATH the host's turnaround, not in front of it.  One bump allocation per copy, reset per
+        # generate() (the previous call ended with a host sync on its tokens, so its copies have been read).
+        self._stage_buf = torch.empty(4 * self.max_len + 4096, dtype=torch.int32).pin_memory() if dev.type == "cuda" else None
+        self._stage_top = 0
         self.state = torch.zeros(2, dtype=torch.int32, device=dev)          # [kv_len, cur]
         self.seen = torch.zeros(V, dtype=torch.uint8, device=dev)
         self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
@@ -369,6 +375,19 @@ class SvlmEngine:
             # 4 x 131k 512: 52.1 (384: 56.7)
             return 128 if hk < 40_000 else (192 if hk < 100_000 else (384 if hk < 200_000 else 512))
         return 128 if hk < 100_000 else (192 if hk < 400_000 else 512)
+
+    # ------------------------------------------------------------------ host -> device staging
+    def _h2d(self, dst: torch.Tensor, src) -> None:
+        """dst.copy_(src) for a 4-byte numpy / torch source, asynchronous on a GPU (staged through the page-locked arena)."""
+        t = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src.contiguous()
+        buf = self._stage_buf
+        if buf is None or t.element_size() != 4 or self._stage_top + t.numel() > buf.numel():
+            dst.copy_(t.view(dst.shape) if t.numel() == dst.numel() else t)
+            return
+        view = buf[self._stage_top:self._stage_top + t.numel()].view(t.dtype).view(t.shape)
+        self._stage_top += t.numel()
+        view.copy_(t)
+        dst.copy_(view, non_blocking=True)
 
     # ------------------------------------------------------------------ cache
     def new_cache(self, page_tokens: Optional[int] = None, slack: Optional[float] = None) -> KVPool:
@@ -695,13 +714,14 @@ class SvlmEngine:
 
         pos_full = np.empty((3, n_rows), dtype=np.float32 if is_f else np.int32)
         on_device = pos_mode == "shrink" and self.device_positions and len(video_grid_thw) <= self.max_spans
-        self.ids_dev[:L_ids].copy_(torch.from_numpy(ids.astype(np.int32)), non_blocking=True)
+        self._stage_top = 0
+        self._h2d(self.ids_dev[:L_ids], ids.astype(np.int32))
         if on_device:
             # shrink mode: positions re-derived from the pruned ids on every chunk (qwen2/model_forward.py:119-126) -- on the device,
             # from the ids and the span grid table; nothing of size L is computed or copied by the host
             n_g = 0 if all_text else len(video_grid_thw)
             if n_g:
-                self.grids_dev[:n_g].copy_(torch.tensor(video_grid_thw, dtype=torch.int32).reshape(n_g, 3), non_blocking=True)
+                self._h2d(self.grids_dev[:n_g], np.asarray(video_grid_thw, dtype=np.int32).reshape(n_g, 3))
             pos_dev = self.posf_dev if is_f else self.pos3_dev
             o.rope_index(self.ids_dev, L_ids, self.grids_dev, n_g, cfg.vision.spatial_merge_size, -1 if all_text else cfg.video_token_id,
                          -1 if all_text else cfg.vision_start_token_id, pos_dev, self.pos_ws, n_extra=max_new_tokens, second_per_grid_t=spg,
@@ -728,7 +748,7 @@ class SvlmEngine:
         if not on_device:
             pos_full[:, L_ids:] = (np.float32(nxt) if is_f else int(nxt)) + np.arange(max_new_tokens, dtype=pos_full.dtype)
             pos_dev = self.posf_dev if is_f else self.pos3_dev
-            pos_dev[:, :n_rows].copy_(torch.from_numpy(pos_full))
+            self._h2d(pos_dev[:, :n_rows], pos_full)
         o.mrope_table(pos_dev, self.inv_freq, self.rope_cs, 0, n_rows, tc.mrope_section)
         cache.reserve(T + max_new_tokens)
         cache.sync_device()
@@ -748,14 +768,15 @@ class SvlmEngine:
                 raise ValueError(f"Video features and video tokens do not match: tokens: {n_tok}, features {vis.shape[0]}")
             idx = idx.copy()
             idx[vmask] = -1 - np.arange(n_tok, dtype=np.int32)
-        idx_dev = torch.from_numpy(idx).to(dev)
+        idx_dev = torch.empty(idx.shape[0], dtype=torch.int32, device=dev)
+        self._h2d(idx_dev, idx)
         # ---- sampling state
         self._penalty = float(repetition_penalty)
         self._suppress = self.eos_dev if suppress_eos else None
         if self._penalty != 1.0:
             self.seen.zero_()
             o.mark_seen(self.ids_dev, L_ids, self.seen)
-        self.state.copy_(torch.tensor([L_ids, -1], dtype=torch.int32))
+        self._h2d(self.state, np.array([L_ids, -1], dtype=np.int32))
         logits_out = [] if keep_logits else None
         # ---- token choice (streaming_generate_qwen.py:75-99): greedy, or HF's warpers + one multinomial draw per token, on the device
         self._sampling = None
@@ -776,7 +797,7 @@ class SvlmEngine:
                 z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
                 z ^= z >> 31
                 self._sample_calls += 1
-                self.rng_dev.copy_(torch.from_numpy(np.array([z & 0xFFFFFFFF, z >> 32], dtype=np.uint32).view(np.int32)))
+                self._h2d(self.rng_dev, np.array([z & 0xFFFFFFFF, z >> 32], dtype=np.uint32).view(np.int32))
 
         # a prompt of tens of thousands of rows (dense-frame prefill) goes through in passes: causal attention over the rows
         # already in the pool makes the passes arithmetically the same forward

@@ -73,6 +73,10 @@ class KVPool:
         self.open_page = -1
         self.open_fill = page_tokens
         self._dirty_from = 0
+        dev_is_gpu = torch.device(device).type == "cuda"
+        self._stage = [torch.empty(self.max_len + 2, dtype=torch.int32).pin_memory() for _ in range(4)] if dev_is_gpu else None
+        self._stage_ev = [None] * 4       # the event behind each buffer's last copy: waited for before the buffer is written again
+        self._stage_i = 0
         self.stats = dict(moved_rows=0, defrags=0, evicted_rows=0)
         KVPool._next_serial += 1
         self.serial = KVPool._next_serial
@@ -199,11 +203,38 @@ class KVPool:
         """Upload the changed tail of slot_of (a few KB, once per chunk, stream-ordered)."""
         lo, hi = self._dirty_from, self.reserved
         if lo < hi:
-            self.slot_of_dev[lo:hi].copy_(torch.from_numpy(self.slot_of[lo:hi].copy()))
+            if self._stage is not None:
+                # page-locked staging, asynchronous copy: a copy from pageable memory makes the host wait for everything enqueued in
+                # front of it (the look-ahead ViT's tail that is meant to run underneath the host's turnaround).  Four buffers in turn:
+                # a generate() call syncs the table at most a few times and ends with a host sync, so a buffer's last copy has been read
+                st = self._stage_next()[:hi - lo]
+                st.copy_(torch.from_numpy(self.slot_of[lo:hi]))
+                self.slot_of_dev[lo:hi].copy_(st, non_blocking=True)
+                self._stage_done()
+            else:
+                self.slot_of_dev[lo:hi].copy_(torch.from_numpy(self.slot_of[lo:hi].copy()))
         self._dirty_from = self.max_len
         if self._lin_dirty:
-            self.lin_len_dev.copy_(torch.tensor([self.lin_valid, int(self.lin_fresh)], dtype=torch.int32))
+            if self._stage is not None:
+                st = self._stage_next()[:2]
+                st[0], st[1] = self.lin_valid, int(self.lin_fresh)
+                self.lin_len_dev.copy_(st, non_blocking=True)
+                self._stage_done()
+            else:
+                self.lin_len_dev.copy_(torch.tensor([self.lin_valid, int(self.lin_fresh)], dtype=torch.int32))
             self._lin_dirty = False
+
+    def _stage_next(self):
+        self._stage_i = (self._stage_i + 1) % len(self._stage)
+        ev = self._stage_ev[self._stage_i]
+        if ev is not None:
+            ev.synchronize()              # (long done in the streaming loop: four syncs and a host sync on the tokens ago)
+        return self._stage[self._stage_i]
+
+    def _stage_done(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stage_ev[self._stage_i] = ev
 
     def fragmentation(self) -> float:
         """Fraction of slots of non-free pages that hold no live row."""
