@@ -767,7 +767,9 @@ __global__ __launch_bounds__(256, 2) void decode_attn_stream_kernel(
 // column pairs (CW = 64/DS): wave w, sub-slot j covers splits (w*SUB + j) + NW*SUB*u, in batches of DA_CB whose loads are ALL
 // issued before anything is consumed (the partials were written by other CUs: every dependent round trip is ~1-2 us of
 // L2/fabric latency, and the kernel is nothing but such round trips).  43 splits (2k keys) on 4 waves = one batch.
+#ifndef DA_CB
 #define DA_CB 12
+#endif
 template <int NW, int DS>
 __global__ __launch_bounds__(NW * 64) void decode_attn_combine_kernel(const float* __restrict__ ws_m, const float* __restrict__ ws_l,
                                                                       const float* __restrict__ ws_acc, const int* __restrict__ len_dev,
