@@ -170,7 +170,9 @@ def main():
 
     t = {}
     counts = []
-    kvlog = []
+    kvlog = []          # KV rows after each answered chunk, read from the cache object at the next chunk's start.  (NOT the driver's
+                        # `ids_log`: that keeps every chunk's full id list -- 31 M Python ints over a 4-hour stream, whose garbage-collector
+                        # passes alone took the chunk from 24.5 to 35.5 ms by chunk 14400)
     kv_steady = [args.sink + args.window]
 
     def fence():
@@ -178,8 +180,40 @@ def main():
 
     stamps = []
 
+    # the host side of the loop is a few hundred microseconds of single-threaded Python per chunk; torch's CPU thread pool (one thread per
+    # core: 256 on these boxes, behind a 16-CPU quota) has nothing to do here and must not wake up for a stray CPU tensor op
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
+    probe = int(os.environ.get("SVLM_BENCH_PROBE", "0"))          # diagnostics: every N chunks, host-side growth indicators on stderr
+    if os.environ.get("SVLM_BENCH_NOGC") == "1":
+        import gc
+        gc.disable()
+
+    prof_at = [int(v) for v in os.environ.get("SVLM_BENCH_CPROFILE", "").split(",") if v]          # diagnostics: cProfile of 300 chunks from each of these
+    prof = {}
+
     def on_chunk(i):
         stamps.append(time.perf_counter())
+        if i in prof_at:
+            import cProfile
+            prof["p"] = cProfile.Profile()
+            prof["p"].enable()
+        if (i - 300) in prof_at and "p" in prof:
+            import pstats, io
+            prof["p"].disable()
+            buf = io.StringIO()
+            pstats.Stats(prof.pop("p"), stream=buf).sort_stats("tottime").print_stats(18)
+            log(f"cProfile of chunks {i - 300}..{i}:\n" + buf.getvalue())
+        if probe and i and i % probe == 0:
+            import gc
+            c0 = time.perf_counter()
+            sum(range(300000))                     # fixed host-only work: does the HOST get slower, whatever the stream does?
+            cal = 1e3 * (time.perf_counter() - c0)
+            log(f"chunk {i}: {1e3 * (stamps[-1] - stamps[-1 - probe]) / probe:.3f} ms/chunk over the last {probe}; host calibration loop {cal:.2f} ms; "
+                f"cuda allocated {torch.cuda.memory_allocated() >> 20} MiB reserved {torch.cuda.memory_reserved() >> 20} MiB; "
+                f"python objects {len(gc.get_objects())}; gc counts {gc.get_count()}")
+        pool = getattr(model._svlm_engine, "_last_cache", None)
+        if pool is not None:
+            kvlog.append({"kv_len": int(pool.length)})
         if i == 0:
             log(f"stream started ({fill} chunks to fill the KV window + {args.warmup} warmup chunks)")
             if dense:
@@ -210,8 +244,9 @@ def main():
                           kv_policy="sink_window", sink=args.sink, window=args.window, do_sample=args.sampling != "greedy",
                           temperature=0.9, top_k={"greedy": None, "temperature": 0, "hf-default": 50}[args.sampling], top_p=1.0,
                           max_new_tokens=args.new_tokens, suppress_eos=True, quiet=True, token_counts=counts, chunk_callback=on_chunk,
-                          ids_log=kvlog, dense_prefill_chunks=dense)
+                          dense_prefill_chunks=dense)
     fence()
+    kvlog.append({"kv_len": int(model._svlm_engine._last_cache.length)})
     kv_steady[0] = kvlog[-1]["kv_len"]
     kv_max = max(e["kv_len"] for e in kvlog)
     pool = getattr(model._svlm_engine, "_last_cache", None)

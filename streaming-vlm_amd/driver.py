@@ -36,6 +36,7 @@ DEFAULT_TEMPERATURE = 0.9
 DEFAULT_REPETITION_PENALTY = 1.05
 MAX_TOKEN_PER_DURATION = 20
 FPS = float(os.environ.get("QWENVL_FPS", "2.0"))       # the reference reads qwen_vl_utils.FPS (env-driven)
+GRID_ROWS_KEPT = 4096          # rows of streaming_args.video_grid_thw kept on an unbounded stream: the first and the last 2048 (see the loop)
 
 
 # ----------------------------------------------------------------------------- WebVTT output (reference: utils/vtt_utils.py:5-16)
@@ -475,7 +476,15 @@ def streaming_inference(model_path="", video_path="", output_dir=None, model_bas
         if streaming_args.video_grid_thw is None:
             streaming_args.video_grid_thw = inputs["video_grid_thw"]
         else:
-            streaming_args.video_grid_thw = torch.cat([streaming_args.video_grid_thw, inputs["video_grid_thw"]], dim=0)
+            g = streaming_args.video_grid_thw
+            if g.shape[0] >= GRID_ROWS_KEPT:
+                # The reference appends one row per chunk for ever (inference.py:415) and reads this tensor in two ways only: from row 0,
+                # one row per surviving vision span (qwen2/pos_emb.py:85-108), and -- when it recomputes -- the rows of the last
+                # retained chunks.  Both ends are kept, the middle goes: on an unbounded stream the tensor stays small (a 4-hour
+                # stream crossed torch's 32768-element threshold for multi-threaded CPU copies at chunk 10923, and on a 256-core host
+                # behind a 16-CPU quota the thread pool that one torch.cat woke up throttled the whole process: 24.4 -> 46 ms per chunk).
+                g = torch.cat([g[:GRID_ROWS_KEPT // 2], g[-(GRID_ROWS_KEPT // 2 - 1):]], dim=0)
+            streaming_args.video_grid_thw = torch.cat([g, inputs["video_grid_thw"]], dim=0)
         current_input_len = new_ids.shape[1]
         _sync(); section_time["INPUT"] += time.perf_counter() - _t
 

@@ -78,6 +78,36 @@ def test_recompute_mode_equals_fresh_prefill(tiny):
     assert [e["new"] for e in log] == [e["new"] for e in log2]      # shrink mode: cached == recomputed
 
 
+def test_grid_history_stays_bounded_on_an_unbounded_stream(tiny, monkeypatch):
+    """The reference appends a row to streaming_args.video_grid_thw per chunk for ever (inference.py:415) and only ever reads its first
+    rows (one per surviving vision span) and, when recomputing, its last ones: the driver keeps both ends and drops the middle.  Same
+    tokens and eviction trace as the ever-growing tensor, sliding window and recompute."""
+    from streaming_vlm_amd import driver as D
+    from streaming_vlm_amd import model as M
+    cfg, sd = tiny
+    seen = []
+    real = M.streaming_generate
+
+    def spy(self, *a, **kw):
+        seen.append(int(kw["streaming_args"].video_grid_thw.shape[0]))
+        return real(self, *a, **kw)
+
+    runs = {}
+    assert D.GRID_ROWS_KEPT == 4096
+    for kept in (4096, 8):
+        monkeypatch.setattr(D, "GRID_ROWS_KEPT", kept)
+        monkeypatch.setattr(M, "streaming_generate", spy)          # (bound to every model object when it is built)
+        seen.clear()
+        a = H.run_engine_stream(_model(cfg, sd), 24)
+        n_a = list(seen)
+        seen.clear()
+        b = H.run_engine_stream(_model(cfg, sd), 12, policy="structural", text_round=100, window_size=3, recompute=True)
+        runs[kept] = ([e["new"] for e in a[3]], a[1], [e["new"] for e in b[3]], n_a, list(seen))
+    full, cut = runs[4096], runs[8]
+    assert full[0] == cut[0] and full[1] == cut[1] and full[2] == cut[2]
+    assert max(full[3]) == 24 and max(cut[3]) <= 8 and max(cut[4]) <= 8
+
+
 def test_time_test_returns_section_times(tiny):
     cfg, sd = tiny
     out = S.streaming_inference(model=_model(cfg, sd), processor=S.SyntheticProcessor(), video_path="synthetic://56x56@1fps",
