@@ -94,6 +94,9 @@ def main(argv=None):
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--out", default=None, help="one JSON with every mode's document (the per-mode files go to output/efficiency/)")
     args = ap.parse_args(argv)
+    # the host side of the loop is single-threaded Python; torch's CPU thread pool (one thread per core) must not wake up for the id
+    # tensors of mode (a) -- beyond 32768 elements every torch.cat would, and behind a CPU quota that throttles the whole process
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
     cfg = {"2b": C.qwen2_vl_2b, "7b": C.qwen2_vl_7b, "2.5-3b": C.qwen2_5_vl_3b, "2.5-7b": C.qwen2_5_vl_7b, "tiny": C.tiny}[args.model]()
     sd = random_state_dict(cfg, 0, "cuda")
     tok = (args.size // 28) ** 2
